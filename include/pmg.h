@@ -1,0 +1,167 @@
+/*
+ * pmg.h -- C ABI of the MI355X-native vectorised multigoal manipulation env.
+ *
+ * This is the drop-in boundary for the reference's per-step hot path.  The
+ * reference (pure Python) crosses into native code through ~25 PyBullet C-API
+ * entry points per env step; this library replaces
+ * that whole inner boundary with ONE batched call per phase.  Each entry
+ * point below cites the reference interface it replaces
+ * (P/ = pybullet_multigoal_gym/ in the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / numpy types.
+ *   - Every function returns 0 on success, a negative PMG_E_* code otherwise;
+ *     the message is available from pmg_last_error().  Nothing aborts or
+ *     throws across this boundary.
+ *   - The caller owns every host buffer passed in; the library owns the
+ *     handle and all device memory.  Buffers named d_* are DEVICE pointers
+ *     (HIP) supplied by the caller (e.g. a torch tensor's data_ptr()).
+ *   - A handle is used from one host thread at a time.  Host-buffer calls
+ *     are synchronous at return; *_device calls are stream-ordered on the
+ *     handle's HIP stream (pmg_sync() waits for it).
+ *   - All arrays are row-major with a leading num_envs axis, float32.
+ */
+#ifndef PMG_H
+#define PMG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* tasks: P/__init__.py:14-35 ('reach','push','pick_and_place','slide','block_stack') */
+enum {
+    PMG_TASK_REACH = 0,
+    PMG_TASK_PUSH = 1,
+    PMG_TASK_PICK_AND_PLACE = 2,
+    PMG_TASK_SLIDE = 3,
+    PMG_TASK_BLOCK_STACK = 4
+};
+
+enum {
+    PMG_OK = 0,
+    PMG_E_INVALID = -1,     /* bad argument / unsupported configuration */
+    PMG_E_DEVICE = -2,      /* HIP runtime error */
+    PMG_E_NOMEM = -3,
+    PMG_E_STATE = -4,       /* call order error (e.g. step before reset) */
+    PMG_E_COMM = -5         /* RCCL error */
+};
+
+/* which output buffer pmg_device_ptr() returns */
+enum {
+    PMG_BUF_OBSERVATION = 0,
+    PMG_BUF_POLICY_STATE = 1,
+    PMG_BUF_ACHIEVED_GOAL = 2,
+    PMG_BUF_DESIRED_GOAL = 3,
+    PMG_BUF_REWARD = 4,
+    PMG_BUF_GOAL_ACHIEVED = 5,   /* uint8 */
+    PMG_BUF_DONE = 6,            /* uint8 */
+    PMG_BUF_PACKED = 7,          /* [N, packed_dim] float32: obs|policy|ag|dg|reward|goal_achieved|done */
+    PMG_BUF_STATE = 8            /* [N, state_dim] float32 persistent simulation state */
+};
+
+/* POD configuration; mirrors the kwargs of pmg.make_env (P/__init__.py:4-11)
+ * that the hot path honours, plus the batch geometry.  Zero-initialise and
+ * set struct_size = sizeof(pmg_config). */
+typedef struct pmg_config {
+    int32_t struct_size;
+    int32_t task;               /* PMG_TASK_* */
+    int32_t num_envs;           /* N: envs simulated by THIS handle (one GPU) */
+    int32_t num_block;          /* block_stack only, 1..5 (P/__init__.py:108) */
+    int32_t binary_reward;      /* P/__init__.py:4 */
+    int32_t joint_control;      /* P/__init__.py:6 */
+    int32_t max_episode_steps;  /* gym TimeLimit, P/__init__.py:6,105 */
+    int32_t device;             /* HIP device ordinal */
+    float distance_threshold;   /* P/__init__.py:6 */
+    int32_t random_order;       /* block_stack, kuka_multi_step_envs.py:7 */
+    uint64_t seed_base;         /* env i is seeded with seed_base + i*seed_stride */
+    uint64_t seed_stride;       /* 0 reproduces the reference (every env seed 0) */
+    int32_t env_index_offset;   /* global index of this shard's env 0 (multi-GPU) */
+    int32_t reserved[7];
+} pmg_config;
+
+typedef struct pmg_dims {
+    int32_t num_envs;
+    int32_t action_dim;      /* kuka.py:103-118 */
+    int32_t observation_dim; /* kuka_single_step_base_env.py:193-221; kuka_multi_step_base_env.py:255-336 */
+    int32_t policy_state_dim;
+    int32_t goal_dim;        /* achieved_goal and desired_goal */
+    int32_t state_dim;       /* floats per env in get_state/set_state */
+    int32_t packed_dim;      /* floats per env in PMG_BUF_PACKED */
+    int32_t reserved;
+} pmg_dims;
+
+typedef struct pmg_env pmg_env;
+
+/* Replaces: pmg.make_env -> gym.make -> TaskEnv.__init__ -> BaseBulletMGEnv.__init__
+ * (P/__init__.py:178; base_env.py:15-110): creates N worlds with the physics
+ * parameters of base_env.py:203-220 and seeds them.  Does NOT perform the
+ * constructor's implicit reset (base_env.py:84); the host layer does. */
+int pmg_create(const pmg_config* cfg, pmg_env** out);
+void pmg_destroy(pmg_env* env);
+int pmg_get_dims(const pmg_env* env, pmg_dims* out);
+const char* pmg_last_error(const pmg_env* env); /* env may be NULL: last create error */
+
+/* Replaces: BaseBulletMGEnv.seed (base_env.py:120-122) == gym.utils.seeding.np_random:
+ * MT19937 seeded by init_by_array(sha512(str(seed))[:8]) per env. */
+int pmg_seed(pmg_env* env, uint64_t seed_base, uint64_t seed_stride);
+
+/* Replaces: BaseBulletMGEnv.reset (base_env.py:124-128) = Kuka.robot_specific_reset
+ * (kuka.py:120-165) + _task_reset/_generate_goal (kuka_single_step_base_env.py:76-148;
+ * kuka_multi_step_base_env.py:183-250; kuka_multi_step_envs.py:34-87) + _get_obs.
+ * mask: N bytes (nonzero = reset this env) or NULL = all.  Output pointers may
+ * be NULL to skip the copy-out. */
+int pmg_reset(pmg_env* env, const uint8_t* mask, float* observation, float* policy_state,
+              float* achieved_goal, float* desired_goal);
+
+/* Replaces: TimeLimit.step -> BaseBulletMGEnv.step (base_env.py:130-138) =
+ * Kuka.apply_action (kuka.py:167-225: tip-delta, clip, IK, motors,
+ * 5 x stepSimulation) + _get_obs + _compute_reward.  actions: [N, action_dim]. */
+int pmg_step(pmg_env* env, const float* actions, float* observation, float* policy_state,
+             float* achieved_goal, float* desired_goal, float* reward, uint8_t* goal_achieved,
+             uint8_t* done);
+
+/* Device-resident variants: inputs already in HBM, outputs stay in the
+ * library's device buffers (pmg_device_ptr).  Stream-ordered, no host sync. */
+int pmg_reset_device(pmg_env* env, const uint8_t* d_mask);
+int pmg_step_device(pmg_env* env, const float* d_actions);
+int pmg_device_ptr(pmg_env* env, int which, void** d_ptr);
+int pmg_stream(pmg_env* env, void** hip_stream);
+int pmg_sync(pmg_env* env);
+/* copy the current output buffers to host (any pointer may be NULL) */
+int pmg_read_outputs(pmg_env* env, float* observation, float* policy_state, float* achieved_goal,
+                     float* desired_goal, float* reward, uint8_t* goal_achieved, uint8_t* done);
+
+/* Replaces: KukaBulletMGEnv._compute_reward (kuka_single_step_base_env.py:237-244;
+ * kuka_multi_step_base_env.py:338-345) on [B, goal_dim] batches (HER relabelling). */
+int pmg_compute_reward(pmg_env* env, const float* achieved_goal, const float* desired_goal,
+                       int64_t batch, float* reward, uint8_t* goal_achieved);
+int pmg_compute_reward_device(pmg_env* env, const float* d_achieved_goal, const float* d_desired_goal,
+                              int64_t batch, float* d_reward, uint8_t* d_goal_achieved);
+
+/* Checkpoint / test hooks (no reference equivalent).
+ * state: [N, state_dim] float32, layout documented in DESIGN.md. */
+int pmg_get_state(pmg_env* env, float* state);
+int pmg_set_state(pmg_env* env, const float* state);
+/* Host-injected goal / object poses for seed-parity tests (replaces the RNG
+ * draws of _generate_goal for the masked envs).  goals: [N, goal_dim]. */
+int pmg_set_goal(pmg_env* env, const uint8_t* mask, const float* goals);
+
+/* Multi-GPU (no reference equivalent): one handle per
+ * rank; the only exchange is an RCCL all-gather of PMG_BUF_PACKED. */
+int pmg_comm_unique_id(uint8_t id[128]);
+int pmg_comm_init(pmg_env* env, int rank, int nranks, const uint8_t id[128]);
+/* d_gathered: [nranks*N, packed_dim] device buffer (caller-owned). */
+int pmg_allgather_packed(pmg_env* env, float* d_gathered);
+
+/* Kernel timing of the most recent *_device call sequence: HIP events on the
+ * handle's stream bracket every step kernel; returns average ms per launch
+ * over the launches since the last pmg_timing_reset(). */
+int pmg_timing_reset(pmg_env* env);
+int pmg_timing_read(pmg_env* env, double* avg_step_kernel_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PMG_H */

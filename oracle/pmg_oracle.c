@@ -1,0 +1,1749 @@
+/*
+ * pmg_oracle.c -- CPU restatement of the reference's per-step hot path.
+ * TEST INFRASTRUCTURE ONLY (see pmg_oracle.h: "PARITY UNPINNED").
+ *
+ * What is restated, and from where (P/ = pybullet_multigoal_gym/ in the reference):
+ *   env orchestration ... P/envs/base_envs/base_env.py:124-138,203-220
+ *   robot ................ P/robots/kuka.py:27,35-51,120-165,167-225,227-301
+ *   single-step tasks .... P/envs/base_envs/kuka_single_step_base_env.py:48-56,76-148,193-244
+ *                          P/envs/task_envs/kuka_single_step_envs.py:4-59
+ *   block stack .......... P/envs/base_envs/kuka_multi_step_base_env.py:62-81,183-250,255-345
+ *                          P/envs/task_envs/kuka_multi_step_envs.py:34-87
+ *   RNG .................. gym 0.17.3 seeding.np_random + numpy RandomState (MT19937)
+ *   physics .............. pybullet~=3.0.6 (NOT in the container): Bullet's
+ *       btMultiBody articulated-body algorithm, btMultiBodyConstraintSolver
+ *       (projected Gauss-Seidel over joint motors, joint limits, contact and
+ *       friction rows), box-box SAT/clipping contacts and BussIK damped
+ *       least squares IK, restated from the published algorithm.  Every such
+ *       statement is tagged [BULLET-PRIOR]; DESIGN.md lists them.
+ */
+#include "pmg_oracle.h"
+#include "../include/pmg_model.h"
+#include "../include/pmg_sha512_const.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifdef PMGO_FLOAT
+typedef float real;
+#define RSQRT sqrtf
+#define RFABS fabsf
+#define RSIN sinf
+#define RCOS cosf
+#define RACOS acosf
+#else
+typedef double real;
+#define RSQRT sqrt
+#define RFABS fabs
+#define RSIN sin
+#define RCOS cos
+#define RACOS acos
+#endif
+
+/* ------------------------------------------------------------------ */
+/* constants                                    */
+/* ------------------------------------------------------------------ */
+#define NJ PMG_NJ
+#define NL PMG_BL_N
+#define NBMAX 5
+#define GRAVITY ((real)9.81)           /* base_env.py:17,215 */
+#define SUBSTEP_DT ((real)0.002)       /* base_env.py:17,217: fixedTimeStep 0.04 / numSubSteps 20 */
+#define SUBSTEPS 20                    /* base_env.py:17,219 */
+#define SIM_STEPS 5                    /* kuka.py:223-225 */
+#define SOLVER_ITERS 5                 /* base_env.py:37,218 */
+#define PHYSICS_DT ((real)0.04)        /* base_env.py:217 (m_physicsDeltaTime) */
+#define CONTACT_ERP ((real)0.9)        /* base_env.py:216 setDefaultContactERP */
+#define JOINT_ERP ((real)0.2)          /* [BULLET-PRIOR] btContactSolverInfo::m_erp default */
+#define LINEAR_SLOP ((real)1e-5)       /* [BULLET-PRIOR] PyBullet createEmptyDynamicsWorld */
+#define RESIDUAL_THRESHOLD ((real)1e-7)/* [BULLET-PRIOR] m_leastSquaresResidualThreshold */
+#define LINK_DAMPING ((real)0.04)      /* [BULLET-PRIOR] btMultiBody m_linearDamping/m_angularDamping */
+#define LIMIT_MAX_IMPULSE ((real)100.0)/* [BULLET-PRIOR] btMultiBodyConstraint m_maxAppliedImpulse */
+#define ARM_KP ((real)0.03)            /* kuka.py:289 */
+#define ARM_KD ((real)1.0)             /* kuka.py:290 */
+#define ARM_FORCE ((real)200.0)        /* kuka.py:288 */
+#define FINGER_FORCE ((real)50.0)      /* kuka.py:299 */
+#define FINGER_LIMIT ((real)0.035)     /* kuka.py:71 */
+#define IK_MAX_ITER 40                 /* kuka.py:278 */
+#define IK_THRESHOLD ((real)1e-5)      /* kuka.py:279 */
+#define IK_DAMPING ((real)0.5)         /* [BULLET-PRIOR] default joint_damping in calculateInverseKinematics */
+#define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0)) /* [BULLET-PRIOR] MaxAngleDLS */
+#define CONTACT_MARGIN ((real)0.002)   /* build choice: speculative-contact distance */
+#define EDGE_FUDGE ((real)1.05)        /* [BULLET-PRIOR] btBoxBoxDetector fudge_factor */
+#define MAX_CONTACTS 64
+#define PI_R ((real)3.14159265358979323846)
+
+static const int JPARENT_BL[NL] = PMG_BL_PARENT;
+static const int BL_TYPE[NL] = PMG_BL_TYPE;
+static const int BL_DOF[NL] = PMG_BL_DOF;
+static const double BL_XYZ[NL][3] = PMG_BL_XYZ;
+static const double BL_ROT[NL][3][3] = PMG_BL_ROT;
+static const double BL_AXIS[NL][3] = PMG_BL_AXIS;
+static const double BL_MASS[NL] = PMG_BL_MASS;
+static const double BL_COM[NL][3] = PMG_BL_COM;
+static const double BL_INERTIA[NL][3] = PMG_BL_INERTIA;
+static const double JLO[NJ] = PMG_JLO;
+static const double JHI[NJ] = PMG_JHI;
+static const double JDAMP[NJ] = PMG_JDAMP;
+static const int ROW_ORDER[18] = PMG_ROW_ORDER;
+static const double FINGER_HALF[3] = PMG_FINGER_HALF;
+static const double TABLE_HALF[3] = PMG_TABLE_HALF;
+static const double BLOCK_HALF[3] = PMG_BLOCK_HALF;
+static const double BLOCK_INERTIA[3] = PMG_BLOCK_INERTIA;
+
+/* kuka.py:27 */
+static const double REST_POSE0[7] = {0, -0.5592432, 0, 1.733180, 0, -0.8501557, 0};
+/* kuka.py:42 (xyzw) */
+static const double TOOL_QUAT[4] = {0, -1, 0, 0};
+
+/* ------------------------------------------------------------------ */
+/* small linear algebra                                                */
+/* ------------------------------------------------------------------ */
+static inline void v3set(real* a, real x, real y, real z) { a[0] = x; a[1] = y; a[2] = z; }
+static inline void v3cpy(real* a, const real* b) { a[0] = b[0]; a[1] = b[1]; a[2] = b[2]; }
+static inline void v3add(real* o, const real* a, const real* b) { o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2]; }
+static inline void v3sub(real* o, const real* a, const real* b) { o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2]; }
+static inline void v3axpy(real* o, real s, const real* a) { o[0] += s * a[0]; o[1] += s * a[1]; o[2] += s * a[2]; }
+static inline real v3dot(const real* a, const real* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void v3cross(real* o, const real* a, const real* b)
+{
+    real x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline real v3norm(const real* a) { return RSQRT(v3dot(a, a)); }
+/* o = R v (R row-major 3x3) */
+static inline void m3v(real* o, const real* R, const real* v)
+{
+    real x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    real y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    real z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3tv(real* o, const real* R, const real* v)
+{
+    real x = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+    real y = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+    real z = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void m3m(real* o, const real* A, const real* B)
+{
+    real t[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    memcpy(o, t, sizeof(t));
+}
+static void quat_to_R(const real* q, real* R) /* q = xyzw */
+{
+    real x = q[0], y = q[1], z = q[2], w = q[3];
+    real d = x * x + y * y + z * z + w * w;
+    real s = (real)2.0 / d;
+    real xs = x * s, ys = y * s, zs = z * s;
+    real wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    R[0] = 1 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+    R[3] = xy + wz; R[4] = 1 - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1 - (xx + yy);
+}
+/* [BULLET-PRIOR] btMatrix3x3::getRotation (Shepperd) */
+static void R_to_quat(const real* m, real* q)
+{
+    real tr = m[0] + m[4] + m[8];
+    if (tr > 0) {
+        real s = RSQRT(tr + 1);
+        q[3] = s * (real)0.5; s = (real)0.5 / s;
+        q[0] = (m[7] - m[5]) * s; q[1] = (m[2] - m[6]) * s; q[2] = (m[3] - m[1]) * s;
+    } else {
+        int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        real s = RSQRT(m[4 * i] - m[4 * j] - m[4 * k] + 1);
+        real t[4];
+        t[i] = s * (real)0.5; s = (real)0.5 / s;
+        t[3] = (m[3 * k + j] - m[3 * j + k]) * s;
+        t[j] = (m[3 * j + i] + m[3 * i + j]) * s;
+        t[k] = (m[3 * k + i] + m[3 * i + k]) * s;
+        q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
+    }
+}
+static void quat_mul(real* o, const real* a, const real* b) /* xyzw, o = a*b */
+{
+    real x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    real y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    real z = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+    real w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+
+/* ------------------------------------------------------------------ */
+/* SHA-512, MT19937, gym seeding, RandomState draws                     */
+/* ------------------------------------------------------------------ */
+static const uint64_t SHA_K[80] = PMG_SHA512_K;
+static const uint64_t SHA_H0[8] = PMG_SHA512_H0;
+#define ROTR64(x, n) (((x) >> (n)) | ((x) << (64 - (n))))
+static void sha512(const uint8_t* msg, size_t len, uint8_t out[64])
+{
+    uint64_t h[8];
+    memcpy(h, SHA_H0, sizeof(h));
+    size_t total = ((len + 17 + 127) / 128) * 128;
+    uint8_t* buf = (uint8_t*)calloc(total, 1);
+    memcpy(buf, msg, len);
+    buf[len] = 0x80;
+    uint64_t bits = (uint64_t)len * 8;
+    for (int i = 0; i < 8; i++) buf[total - 1 - i] = (uint8_t)(bits >> (8 * i));
+    for (size_t off = 0; off < total; off += 128) {
+        uint64_t w[80];
+        for (int i = 0; i < 16; i++) {
+            uint64_t v = 0;
+            for (int b = 0; b < 8; b++) v = (v << 8) | buf[off + 8 * i + b];
+            w[i] = v;
+        }
+        for (int i = 16; i < 80; i++) {
+            uint64_t s0 = ROTR64(w[i - 15], 1) ^ ROTR64(w[i - 15], 8) ^ (w[i - 15] >> 7);
+            uint64_t s1 = ROTR64(w[i - 2], 19) ^ ROTR64(w[i - 2], 61) ^ (w[i - 2] >> 6);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint64_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 80; i++) {
+            uint64_t S1 = ROTR64(e, 14) ^ ROTR64(e, 18) ^ ROTR64(e, 41);
+            uint64_t ch = (e & f) ^ (~e & g);
+            uint64_t t1 = hh + S1 + ch + SHA_K[i] + w[i];
+            uint64_t S0 = ROTR64(a, 28) ^ ROTR64(a, 34) ^ ROTR64(a, 39);
+            uint64_t mj = (a & b) ^ (a & c) ^ (b & c);
+            uint64_t t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    free(buf);
+    for (int i = 0; i < 8; i++)
+        for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(h[i] >> (56 - 8 * b));
+}
+
+typedef struct {
+    uint32_t mt[624];
+    int idx;
+} mt19937;
+
+static void mt_init_genrand(mt19937* s, uint32_t seed)
+{
+    s->mt[0] = seed;
+    for (int i = 1; i < 624; i++) s->mt[i] = 1812433253U * (s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) + (uint32_t)i;
+    s->idx = 624;
+}
+static void mt_init_by_array(mt19937* s, const uint32_t* key, int klen)
+{
+    mt_init_genrand(s, 19650218U);
+    int i = 1, j = 0;
+    int k = 624 > klen ? 624 : klen;
+    for (; k; k--) {
+        s->mt[i] = (s->mt[i] ^ ((s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) * 1664525U)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { s->mt[0] = s->mt[623]; i = 1; }
+        if (j >= klen) j = 0;
+    }
+    for (k = 623; k; k--) {
+        s->mt[i] = (s->mt[i] ^ ((s->mt[i - 1] ^ (s->mt[i - 1] >> 30)) * 1566083941U)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { s->mt[0] = s->mt[623]; i = 1; }
+    }
+    s->mt[0] = 0x80000000U;
+    s->idx = 624;
+}
+static uint32_t mt_next(mt19937* s)
+{
+    if (s->idx >= 624) {
+        uint32_t* mt = s->mt;
+        int kk;
+        for (kk = 0; kk < 624 - 397; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+            mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+        }
+        for (; kk < 623; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000U) | (mt[kk + 1] & 0x7fffffffU);
+            mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+        }
+        uint32_t y = (mt[623] & 0x80000000U) | (mt[0] & 0x7fffffffU);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1U) ? 0x9908b0dfU : 0U);
+        s->idx = 0;
+    }
+    uint32_t y = s->mt[s->idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680U;
+    y ^= (y << 15) & 0xefc60000U;
+    y ^= (y >> 18);
+    return y;
+}
+/* numpy RandomState.random_sample */
+static double mt_double(mt19937* s)
+{
+    uint32_t a = mt_next(s) >> 5, b = mt_next(s) >> 6;
+    return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+/* numpy RandomState.uniform(low, high): low + (high-low)*random_sample() */
+static double mt_uniform(mt19937* s, double lo, double hi) { return lo + (hi - lo) * mt_double(s); }
+/* numpy legacy random_interval (masked rejection, 32-bit path) */
+static uint32_t mt_interval(mt19937* s, uint32_t max)
+{
+    if (max == 0) return 0;
+    uint32_t mask = max;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    while ((v = (mt_next(s) & mask)) > max) {}
+    return v;
+}
+/* gym.utils.seeding.np_random(seed): RandomState seeded with the uint32 words of
+ * sha512(str(seed))[:8] (little endian), high zero words dropped */
+static void gym_seed(mt19937* s, uint64_t seed)
+{
+    char txt[32];
+    int n = snprintf(txt, sizeof(txt), "%llu", (unsigned long long)seed);
+    uint8_t dig[64];
+    sha512((const uint8_t*)txt, (size_t)n, dig);
+    uint32_t w0 = (uint32_t)dig[0] | ((uint32_t)dig[1] << 8) | ((uint32_t)dig[2] << 16) | ((uint32_t)dig[3] << 24);
+    uint32_t w1 = (uint32_t)dig[4] | ((uint32_t)dig[5] << 8) | ((uint32_t)dig[6] << 16) | ((uint32_t)dig[7] << 24);
+    uint32_t key[2] = {w0, w1};
+    int klen = w1 ? 2 : 1; /* _int_list_from_bigint drops high zeros; bigint 0 -> [0] */
+    mt_init_by_array(s, key, klen);
+}
+
+void pmgo_rng_probe(uint64_t seed, int n_double, double* out_double, int shuffle_n, int32_t* out_perm)
+{
+    mt19937 s;
+    gym_seed(&s, seed);
+    for (int i = 0; i < n_double; i++) out_double[i] = mt_double(&s);
+    for (int i = 0; i < shuffle_n; i++) out_perm[i] = i;
+    for (int i = shuffle_n - 1; i >= 1; i--) {
+        uint32_t j = mt_interval(&s, (uint32_t)i);
+        int32_t t = out_perm[i]; out_perm[i] = out_perm[j]; out_perm[j] = t;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* kinematics of the 17-link PyBullet tree                             */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    real R[NL][9];   /* world <- link frame */
+    real p[NL][3];   /* link frame origin, world */
+    real c[NL][3];   /* link COM, world */
+    real S[NJ][6];   /* joint motion subspace, world coords about the world origin: [w; v_O] */
+    real axis[NJ][3];
+} Kin;
+
+static void kinematics(const real* q, Kin* k)
+{
+    for (int i = 0; i < NL; i++) {
+        int par = JPARENT_BL[i];
+        real Rp[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pp[3] = {0, 0, 0};
+        if (par >= 0) { memcpy(Rp, k->R[par], sizeof(Rp)); v3cpy(pp, k->p[par]); }
+        real Rj[9], xyz[3], ax[3];
+        for (int a = 0; a < 3; a++) {
+            xyz[a] = (real)BL_XYZ[i][a]; ax[a] = (real)BL_AXIS[i][a];
+            for (int b = 0; b < 3; b++) Rj[3 * a + b] = (real)BL_ROT[i][a][b];
+        }
+        real R0[9];
+        m3m(R0, Rp, Rj);
+        real off[3];
+        m3v(off, Rp, xyz);
+        v3add(k->p[i], pp, off);
+        int d = BL_DOF[i];
+        if (BL_TYPE[i] == 0) { /* revolute about axis (here always local z) */
+            real cq = RCOS(q[d]), sq = RSIN(q[d]);
+            real x = ax[0], y = ax[1], z = ax[2], t = 1 - cq;
+            real Rq[9] = {t * x * x + cq, t * x * y - sq * z, t * x * z + sq * y,
+                          t * x * y + sq * z, t * y * y + cq, t * y * z - sq * x,
+                          t * x * z - sq * y, t * y * z + sq * x, t * z * z + cq};
+            m3m(k->R[i], R0, Rq);
+        } else {
+            memcpy(k->R[i], R0, sizeof(R0));
+            if (BL_TYPE[i] == 1) {
+                real aw[3];
+                m3v(aw, R0, ax);
+                v3axpy(k->p[i], q[d], aw);
+            }
+        }
+        real com[3] = {(real)BL_COM[i][0], (real)BL_COM[i][1], (real)BL_COM[i][2]}, cw[3];
+        m3v(cw, k->R[i], com);
+        v3add(k->c[i], k->p[i], cw);
+        if (d >= 0) {
+            real aw[3];
+            m3v(aw, k->R[i], ax);
+            v3cpy(k->axis[d], aw);
+            if (BL_TYPE[i] == 0) {
+                v3cpy(k->S[d], aw);
+                v3cross(k->S[d] + 3, k->p[i], aw); /* v_O = p x a */
+            } else {
+                v3set(k->S[d], 0, 0, 0);
+                v3cpy(k->S[d] + 3, aw);
+            }
+        }
+    }
+}
+
+/* is dof d an ancestor-or-self joint of Bullet link L? */
+static int dof_affects_link(int d, int L)
+{
+    int i = L;
+    while (i >= 0) {
+        if (BL_DOF[i] == d) return 1;
+        i = JPARENT_BL[i];
+    }
+    return 0;
+}
+
+/* row of the point Jacobian: (d/dq_d of the world velocity of point r fixed on link L) . n */
+static void point_jacobian(const Kin* k, int L, const real* r, const real* n, real* J)
+{
+    for (int d = 0; d < NJ; d++) {
+        J[d] = 0;
+        if (!dof_affects_link(d, L)) continue;
+        real v[3];
+        v3cross(v, k->S[d], r); /* w x r */
+        v3add(v, v, k->S[d] + 3);
+        J[d] = v3dot(v, n);
+    }
+}
+static void point_velocity(const Kin* k, const real* qd, int L, const real* r, real* vlin, real* w)
+{
+    v3set(vlin, 0, 0, 0);
+    v3set(w, 0, 0, 0);
+    for (int d = 0; d < NJ; d++) {
+        if (!dof_affects_link(d, L)) continue;
+        real v[3];
+        v3cross(v, k->S[d], r);
+        v3add(v, v, k->S[d] + 3);
+        v3axpy(vlin, qd[d], v);
+        v3axpy(w, qd[d], k->S[d]);
+    }
+}
+
+void pmgo_fk_tip(const double q[9], double pos[3], double rot[9])
+{
+    real qq[NJ];
+    for (int i = 0; i < NJ; i++) qq[i] = (real)q[i];
+    Kin k;
+    kinematics(qq, &k);
+    for (int i = 0; i < 3; i++) pos[i] = k.p[PMG_BL_TIP][i];
+    for (int i = 0; i < 9; i++) rot[i] = k.R[PMG_BL_TIP][i];
+}
+
+/* ------------------------------------------------------------------ */
+/* articulated-body algorithm, world coordinates                       */
+/* [BULLET-PRIOR] btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    real U[NJ][6];
+    real D[NJ];
+} AbaCache;
+
+static void sp_crm(real* o, const real* v, const real* m) /* motion x motion */
+{
+    real a[3], b[3], c[3];
+    v3cross(a, v, m);
+    v3cross(b, v, m + 3);
+    v3cross(c, v + 3, m);
+    v3cpy(o, a);
+    v3add(o + 3, b, c);
+}
+static void sp_crf(real* o, const real* v, const real* f) /* motion x* force */
+{
+    real a[3], b[3], c[3];
+    v3cross(a, v, f);
+    v3cross(b, v + 3, f + 3);
+    v3cross(c, v, f + 3);
+    v3add(o, a, b);
+    v3cpy(o + 3, c);
+}
+static void mat6v(real* o, const real* M, const real* v)
+{
+    real t[6];
+    for (int i = 0; i < 6; i++) {
+        real s = 0;
+        for (int j = 0; j < 6; j++) s += M[6 * i + j] * v[j];
+        t[i] = s;
+    }
+    memcpy(o, t, sizeof(t));
+}
+/* spatial inertia about the world origin of a body (mass m, COM c, rotational inertia Ic world) */
+static void spatial_inertia(real* I, real m, const real* c, const real* Ic)
+{
+    real cx[9] = {0, -c[2], c[1], c[2], 0, -c[0], -c[1], c[0], 0};
+    memset(I, 0, 36 * sizeof(real));
+    real cc = v3dot(c, c);
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            I[6 * a + b] = Ic[3 * a + b] + m * ((a == b ? cc : 0) - c[a] * c[b]);
+            I[6 * a + 3 + b] = m * cx[3 * a + b];
+            I[6 * (3 + a) + b] = m * cx[3 * b + a];
+        }
+    for (int a = 0; a < 3; a++) I[6 * (3 + a) + 3 + a] = m;
+}
+
+/* forward dynamics: qdd = M^-1 (tau - bias) with gravity + Bullet's per-link damping */
+static void aba(const Kin* k, const real* qd, const real* tau, real* qdd, AbaCache* cache)
+{
+    static const real zero6[6] = {0, 0, 0, 0, 0, 0};
+    real v[NL][6], cb[NL][6], IA[NL][36], pA[NL][6], u[NJ];
+    for (int i = 0; i < NL; i++) {
+        int par = JPARENT_BL[i], d = BL_DOF[i];
+        memcpy(v[i], par >= 0 ? v[par] : zero6, sizeof(zero6));
+        memset(cb[i], 0, sizeof(zero6));
+        if (d >= 0) {
+            real vj[6];
+            for (int a = 0; a < 6; a++) vj[a] = k->S[d][a] * qd[d];
+            for (int a = 0; a < 6; a++) v[i][a] += vj[a];
+            sp_crm(cb[i], v[i], vj);
+        }
+        /* world rotational inertia about the COM */
+        real Ic[9], tmp[9];
+        const real* R = k->R[i];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) tmp[3 * a + b] = R[3 * a + b] * (real)BL_INERTIA[i][b];
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++)
+                Ic[3 * a + b] = tmp[3 * a] * R[3 * b] + tmp[3 * a + 1] * R[3 * b + 1] + tmp[3 * a + 2] * R[3 * b + 2];
+        real m = (real)BL_MASS[i];
+        spatial_inertia(IA[i], m, k->c[i], Ic);
+        real h[6];
+        mat6v(h, IA[i], v[i]);
+        sp_crf(pA[i], v[i], h);
+        /* external: gravity at the COM + Bullet link damping (k1 = k2 = 0.04) */
+        real vc[3], w[3];
+        v3cpy(w, v[i]);
+        v3cross(vc, w, k->c[i]);
+        v3add(vc, vc, v[i] + 3);
+        real f[3], n[3], Iw[3];
+        real kl = LINK_DAMPING * (1 + v3norm(vc)), ka = LINK_DAMPING * (1 + v3norm(w));
+        v3set(f, -m * vc[0] * kl, -m * vc[1] * kl, m * (-GRAVITY) - m * vc[2] * kl);
+        m3v(Iw, Ic, w);
+        v3set(n, -Iw[0] * ka, -Iw[1] * ka, -Iw[2] * ka);
+        real cf[3];
+        v3cross(cf, k->c[i], f);
+        v3add(n, n, cf);
+        for (int a = 0; a < 3; a++) { pA[i][a] -= n[a]; pA[i][3 + a] -= f[a]; }
+    }
+    for (int i = NL - 1; i >= 0; i--) {
+        int par = JPARENT_BL[i], d = BL_DOF[i];
+        real Ia[36], pa[6];
+        if (d >= 0) {
+            real* U = cache->U[d];
+            mat6v(U, IA[i], k->S[d]);
+            real D = 0, sp = 0;
+            for (int a = 0; a < 6; a++) { D += k->S[d][a] * U[a]; sp += k->S[d][a] * pA[i][a]; }
+            cache->D[d] = D;
+            u[d] = tau[d] - sp;
+            for (int a = 0; a < 6; a++)
+                for (int b = 0; b < 6; b++) Ia[6 * a + b] = IA[i][6 * a + b] - U[a] * U[b] / D;
+            real Iac[6];
+            mat6v(Iac, Ia, cb[i]);
+            for (int a = 0; a < 6; a++) pa[a] = pA[i][a] + Iac[a] + U[a] * u[d] / D;
+        } else {
+            memcpy(Ia, IA[i], sizeof(Ia));
+            memcpy(pa, pA[i], sizeof(pa));
+        }
+        if (par >= 0) {
+            for (int a = 0; a < 36; a++) IA[par][a] += Ia[a];
+            for (int a = 0; a < 6; a++) pA[par][a] += pa[a];
+        }
+    }
+    real acc[NL][6];
+    for (int i = 0; i < NL; i++) {
+        int par = JPARENT_BL[i], d = BL_DOF[i];
+        for (int a = 0; a < 6; a++) acc[i][a] = (par >= 0 ? acc[par][a] : 0) + cb[i][a];
+        if (d >= 0) {
+            real ua = 0;
+            for (int a = 0; a < 6; a++) ua += cache->U[d][a] * acc[i][a];
+            qdd[d] = (u[d] - ua) / cache->D[d];
+            for (int a = 0; a < 6; a++) acc[i][a] += k->S[d][a] * qdd[d];
+        }
+    }
+}
+
+/* impulse response out = M^-1 f using the cached articulated quantities.
+ * [BULLET-PRIOR] btMultiBody::calcAccelerationDeltasMultiDof */
+static void aba_response(const Kin* k, const AbaCache* cache, const real* f, real* out)
+{
+    real pA[NL][6], u[NJ], acc[NL][6];
+    memset(pA, 0, sizeof(pA));
+    for (int i = NL - 1; i >= 0; i--) {
+        int par = JPARENT_BL[i], d = BL_DOF[i];
+        real pa[6];
+        memcpy(pa, pA[i], sizeof(pa));
+        if (d >= 0) {
+            real sp = 0;
+            for (int a = 0; a < 6; a++) sp += k->S[d][a] * pA[i][a];
+            u[d] = f[d] - sp;
+            for (int a = 0; a < 6; a++) pa[a] += cache->U[d][a] * u[d] / cache->D[d];
+        }
+        if (par >= 0)
+            for (int a = 0; a < 6; a++) pA[par][a] += pa[a];
+    }
+    for (int i = 0; i < NL; i++) {
+        int par = JPARENT_BL[i], d = BL_DOF[i];
+        for (int a = 0; a < 6; a++) acc[i][a] = par >= 0 ? acc[par][a] : 0;
+        if (d >= 0) {
+            real ua = 0;
+            for (int a = 0; a < 6; a++) ua += cache->U[d][a] * acc[i][a];
+            out[d] = (u[d] - ua) / cache->D[d];
+            for (int a = 0; a < 6; a++) acc[i][a] += k->S[d][a] * out[d];
+        }
+    }
+}
+
+void pmgo_fdyn(const double q[9], const double qd[9], const double tau[9], double qdd[9])
+{
+    real qq[NJ], vv[NJ], tt[NJ], aa[NJ];
+    for (int i = 0; i < NJ; i++) { qq[i] = (real)q[i]; vv[i] = (real)qd[i]; tt[i] = (real)tau[i]; }
+    Kin k;
+    AbaCache c;
+    kinematics(qq, &k);
+    aba(&k, vv, tt, aa, &c);
+    for (int i = 0; i < NJ; i++) qdd[i] = aa[i];
+}
+void pmgo_minv(const double q[9], double minv[81])
+{
+    real qq[NJ], z[NJ], aa[NJ];
+    for (int i = 0; i < NJ; i++) { qq[i] = (real)q[i]; z[i] = 0; }
+    Kin k;
+    AbaCache c;
+    kinematics(qq, &k);
+    aba(&k, z, z, aa, &c);
+    for (int j = 0; j < NJ; j++) {
+        real f[NJ], o[NJ];
+        for (int i = 0; i < NJ; i++) f[i] = (i == j);
+        aba_response(&k, &c, f, o);
+        for (int i = 0; i < NJ; i++) minv[9 * i + j] = o[i];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* inverse kinematics                                                   */
+/* [BULLET-PRIOR] PhysicsServerCommandProcessor::processCalculateInverseKinematics +
+ * IKTrajectoryHelper::computeIK, method IK2_VEL_DLS_WITH_ORIENTATION (the 7-entry
+ * null-space lists of kuka.py:272-277 do not match the 9 dofs, so pybullet.c drops
+ * them), Jacobian::CalcDeltaThetasDLS2 with per-joint damping 0.5.           */
+/* ------------------------------------------------------------------ */
+static int solve_linear(int n, real* A, real* b) /* Gaussian elimination, partial pivoting; A n x n row-major */
+{
+    for (int c = 0; c < n; c++) {
+        int piv = c;
+        real best = RFABS(A[n * c + c]);
+        for (int r = c + 1; r < n; r++)
+            if (RFABS(A[n * r + c]) > best) { best = RFABS(A[n * r + c]); piv = r; }
+        if (best == 0) return -1;
+        if (piv != c) {
+            for (int j = 0; j < n; j++) { real t = A[n * c + j]; A[n * c + j] = A[n * piv + j]; A[n * piv + j] = t; }
+            real t = b[c]; b[c] = b[piv]; b[piv] = t;
+        }
+        for (int r = c + 1; r < n; r++) {
+            real f = A[n * r + c] / A[n * c + c];
+            for (int j = c; j < n; j++) A[n * r + j] -= f * A[n * c + j];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int r = n - 1; r >= 0; r--) {
+        real s = b[r];
+        for (int j = r + 1; j < n; j++) s -= A[n * r + j] * b[j];
+        b[r] = s / A[n * r + r];
+    }
+    return 0;
+}
+
+static int ik_solve(const real* q_start, const real* target, const real* tquat, int max_iter, real thr, real* q_out)
+{
+    real q[NJ];
+    memcpy(q, q_start, sizeof(q));
+    real diff = (real)1e30;
+    int it = 0;
+    for (; it < max_iter && diff > thr; it++) {
+        Kin k;
+        kinematics(q, &k);
+        const real* p = k.p[PMG_BL_TIP];
+        real e[6];
+        v3sub(e, target, p);
+        diff = v3norm(e);
+        /* orientation error: deltaQ = endQ * startQ^-1, angle*axis */
+        real sq[4], si[4], dq[4];
+        R_to_quat(k.R[PMG_BL_TIP], sq);
+        si[0] = -sq[0]; si[1] = -sq[1]; si[2] = -sq[2]; si[3] = sq[3];
+        quat_mul(dq, tquat, si);
+        real w = dq[3] < -1 ? -1 : (dq[3] > 1 ? 1 : dq[3]);
+        real angle = 2 * RACOS(w);
+        real s2 = 1 - dq[3] * dq[3];
+        real ax[3] = {1, 0, 0};
+        if (s2 >= (real)10.0 * (real)2.220446049250313e-16) {
+            real s = 1 / RSQRT(s2);
+            v3set(ax, dq[0] * s, dq[1] * s, dq[2] * s);
+        }
+        if (angle > PI_R) angle -= 2 * PI_R;
+        real an = v3norm(ax);
+        for (int a = 0; a < 3; a++) e[3 + a] = angle * ax[a] / an;
+        /* Jacobian 6 x 9 of the tip link frame */
+        real J[6][NJ];
+        for (int d = 0; d < NJ; d++) {
+            if (!dof_affects_link(d, PMG_BL_TIP)) {
+                for (int r = 0; r < 6; r++) J[r][d] = 0;
+                continue;
+            }
+            real v[3];
+            v3cross(v, k.S[d], p);
+            v3add(v, v, k.S[d] + 3);
+            for (int a = 0; a < 3; a++) { J[a][d] = v[a]; J[3 + a][d] = k.S[d][a]; }
+        }
+        real U[NJ * NJ], rhs[NJ];
+        for (int a = 0; a < NJ; a++) {
+            for (int b = 0; b < NJ; b++) {
+                real s = 0;
+                for (int r = 0; r < 6; r++) s += J[r][a] * J[r][b];
+                U[NJ * a + b] = s + (a == b ? IK_DAMPING : 0);
+            }
+            real s = 0;
+            for (int r = 0; r < 6; r++) s += J[r][a] * e[r];
+            rhs[a] = s;
+        }
+        solve_linear(NJ, U, rhs);
+        real mx = 0;
+        for (int a = 0; a < NJ; a++) mx = RFABS(rhs[a]) > mx ? RFABS(rhs[a]) : mx;
+        if (mx > IK_MAX_STEP)
+            for (int a = 0; a < NJ; a++) rhs[a] *= IK_MAX_STEP / mx;
+        for (int a = 0; a < NJ; a++) q[a] += rhs[a];
+    }
+    memcpy(q_out, q, sizeof(q));
+    return it;
+}
+
+int pmgo_ik(const double q_start[9], const double target_pos[3], const double target_quat_xyzw[4], int max_iter,
+            double threshold, double q_out[9])
+{
+    real q[NJ], t[3], tq[4], o[NJ];
+    for (int i = 0; i < NJ; i++) q[i] = (real)q_start[i];
+    for (int i = 0; i < 3; i++) t[i] = (real)target_pos[i];
+    for (int i = 0; i < 4; i++) tq[i] = (real)target_quat_xyzw[i];
+    int it = ik_solve(q, t, tq, max_iter, (real)threshold, o);
+    for (int i = 0; i < NJ; i++) q_out[i] = o[i];
+    return it;
+}
+
+/* ------------------------------------------------------------------ */
+/* box-box narrowphase: SAT over 15 axes + face clipping / edge-edge     */
+/* [BULLET-PRIOR] btBoxBoxDetector (ODE dBoxBox2): same axis test, edge
+ * fudge factor and <=4 contacts; the persistent manifold is replaced by
+ * regeneration every substep with a CONTACT_MARGIN speculative distance. */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    real pa[3], pb[3]; /* world points on A and on B */
+    real n[3];         /* unit normal pointing from B to A */
+    real dist;         /* signed distance (negative = penetration) */
+} CPoint;
+
+static int clip_poly(const real (*in)[2], int n, real (*out)[2], int axis, real sign, real lim)
+{
+    /* keep sign*p[axis] <= lim */
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const real* a = in[i];
+        const real* b = in[(i + 1) % n];
+        real da = sign * a[axis] - lim, db = sign * b[axis] - lim;
+        if (da <= 0) { out[m][0] = a[0]; out[m][1] = a[1]; m++; }
+        if ((da < 0 && db > 0) || (da > 0 && db < 0)) {
+            real t = da / (da - db);
+            out[m][0] = a[0] + t * (b[0] - a[0]);
+            out[m][1] = a[1] + t * (b[1] - a[1]);
+            m++;
+        }
+    }
+    return m;
+}
+
+static int box_box(const real* ca, const real* Ra, const real* ha, const real* cb, const real* Rb, const real* hb,
+                   real margin, CPoint* out)
+{
+    real A[3][3], B[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int a = 0; a < 3; a++) { A[i][a] = Ra[3 * a + i]; B[i][a] = Rb[3 * a + i]; }
+    real d[3];
+    v3sub(d, cb, ca);
+    real C[3][3], Q[3][3], dA[3], dB[3];
+    for (int i = 0; i < 3; i++) {
+        dA[i] = v3dot(d, A[i]);
+        dB[i] = v3dot(d, B[i]);
+        for (int j = 0; j < 3; j++) { C[i][j] = v3dot(A[i], B[j]); Q[i][j] = RFABS(C[i][j]); }
+    }
+    real best = (real)-1e30;
+    int code = -1;
+    real nrm[3] = {0, 0, 0}; /* axis direction from A towards B */
+    for (int i = 0; i < 3; i++) {
+        real s = RFABS(dA[i]) - (ha[i] + hb[0] * Q[i][0] + hb[1] * Q[i][1] + hb[2] * Q[i][2]);
+        if (s > margin) return 0;
+        if (s > best) { best = s; code = i; real sg = dA[i] < 0 ? (real)-1 : (real)1; v3set(nrm, sg * A[i][0], sg * A[i][1], sg * A[i][2]); }
+    }
+    for (int j = 0; j < 3; j++) {
+        real s = RFABS(dB[j]) - (hb[j] + ha[0] * Q[0][j] + ha[1] * Q[1][j] + ha[2] * Q[2][j]);
+        if (s > margin) return 0;
+        if (s > best) { best = s; code = 3 + j; real sg = dB[j] < 0 ? (real)-1 : (real)1; v3set(nrm, sg * B[j][0], sg * B[j][1], sg * B[j][2]); }
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            real L[3];
+            v3cross(L, A[i], B[j]);
+            real len = v3norm(L);
+            if (len < (real)1e-6) continue;
+            real proj = v3dot(d, L);
+            real ra = ha[i1] * Q[i2][j] + ha[i2] * Q[i1][j];
+            real rb = hb[j1] * Q[i][j2] + hb[j2] * Q[i][j1];
+            real s = (RFABS(proj) - (ra + rb)) / len;
+            if (s > margin) return 0;
+            /* edges must beat the best face by the fudge factor (penetrations scaled up, gaps scaled down) */
+            real pen = s < 0 ? s * EDGE_FUDGE : s / EDGE_FUDGE;
+            if (pen > best) {
+                best = s; code = 6 + 3 * i + j;
+                real sg = proj < 0 ? (real)-1 : (real)1;
+                v3set(nrm, sg * L[0] / len, sg * L[1] / len, sg * L[2] / len);
+            }
+        }
+    if (code < 0) return 0;
+    if (code >= 6) {
+        int i = (code - 6) / 3, j = (code - 6) % 3;
+        real pa[3], pb[3];
+        v3cpy(pa, ca);
+        v3cpy(pb, cb);
+        for (int kx = 0; kx < 3; kx++) {
+            if (kx != i) { real sg = v3dot(nrm, A[kx]) > 0 ? (real)1 : (real)-1; v3axpy(pa, sg * ha[kx], A[kx]); }
+            if (kx != j) { real sg = v3dot(nrm, B[kx]) > 0 ? (real)-1 : (real)1; v3axpy(pb, sg * hb[kx], B[kx]); }
+        }
+        /* closest points of lines pa + s A[i], pb + t B[j] */
+        real r[3];
+        v3sub(r, pb, pa);
+        real uaub = C[i][j], q1 = v3dot(A[i], r), q2 = -v3dot(B[j], r);
+        real den = 1 - uaub * uaub;
+        real s = 0, t = 0;
+        if (den > (real)1e-8) { s = (q1 + uaub * q2) / den; t = (uaub * q1 + q2) / den; }
+        v3axpy(pa, s, A[i]);
+        v3axpy(pb, t, B[j]);
+        v3cpy(out[0].pa, pa);
+        v3cpy(out[0].pb, pb);
+        v3set(out[0].n, -nrm[0], -nrm[1], -nrm[2]);
+        out[0].dist = best;
+        return 1;
+    }
+    /* face contact: reference box owns the axis */
+    int refA = code < 3;
+    const real *cr = refA ? ca : cb, *ci = refA ? cb : ca, *hr = refA ? ha : hb, *hi = refA ? hb : ha;
+    real (*Rr)[3] = refA ? A : B;
+    real (*Ri)[3] = refA ? B : A;
+    int ax = refA ? code : code - 3;
+    real nr[3]; /* outward reference-face normal, pointing at the incident box */
+    if (refA) v3cpy(nr, nrm); else v3set(nr, -nrm[0], -nrm[1], -nrm[2]);
+    /* incident face: most anti-parallel axis */
+    int ia = 0;
+    real bestd = -1;
+    for (int kx = 0; kx < 3; kx++) {
+        real dd = RFABS(v3dot(nr, Ri[kx]));
+        if (dd > bestd) { bestd = dd; ia = kx; }
+    }
+    real isg = v3dot(nr, Ri[ia]) > 0 ? (real)-1 : (real)1;
+    int iu = (ia + 1) % 3, iv = (ia + 2) % 3, ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+    real fc[3];
+    v3cpy(fc, ci);
+    v3axpy(fc, isg * hi[ia], Ri[ia]);
+    real poly[8][2], tmp[8][2];
+    static const real SU[4] = {1, -1, -1, 1}, SV[4] = {1, 1, -1, -1};
+    real vz[4];
+    for (int c = 0; c < 4; c++) {
+        real v[3], rel[3];
+        v3cpy(v, fc);
+        v3axpy(v, SU[c] * hi[iu], Ri[iu]);
+        v3axpy(v, SV[c] * hi[iv], Ri[iv]);
+        v3sub(rel, v, cr);
+        poly[c][0] = v3dot(rel, Rr[ru]);
+        poly[c][1] = v3dot(rel, Rr[rv]);
+        vz[c] = v3dot(rel, nr);
+    }
+    /* plane of the incident face in reference coords: z = z0 + gu*u + gv*v */
+    real e1u = poly[1][0] - poly[0][0], e1v = poly[1][1] - poly[0][1], e1z = vz[1] - vz[0];
+    real e2u = poly[3][0] - poly[0][0], e2v = poly[3][1] - poly[0][1], e2z = vz[3] - vz[0];
+    real det = e1u * e2v - e1v * e2u;
+    real gu = 0, gv = 0;
+    if (RFABS(det) > (real)1e-12) { gu = (e1z * e2v - e2z * e1v) / det; gv = (e2z * e1u - e1z * e2u) / det; }
+    real z0 = vz[0] - gu * poly[0][0] - gv * poly[0][1];
+    int n = 4;
+    n = clip_poly(poly, n, tmp, 0, 1, hr[ru]);
+    n = clip_poly(tmp, n, poly, 0, -1, hr[ru]);
+    n = clip_poly(poly, n, tmp, 1, 1, hr[rv]);
+    n = clip_poly(tmp, n, poly, 1, -1, hr[rv]);
+    real pts[8][3], sep[8];
+    int m = 0;
+    for (int c = 0; c < n; c++) {
+        real z = z0 + gu * poly[c][0] + gv * poly[c][1];
+        real s = z - hr[ax];
+        if (s > margin) continue;
+        pts[m][0] = poly[c][0]; pts[m][1] = poly[c][1]; pts[m][2] = z;
+        sep[m] = s;
+        m++;
+    }
+    if (m == 0) return 0;
+    int sel[4], ns = 0;
+    if (m <= 4) {
+        for (int c = 0; c < m; c++) sel[ns++] = c;
+    } else {
+        /* deepest, farthest from it, then largest triangle on either side */
+        int i0 = 0;
+        for (int c = 1; c < m; c++) if (sep[c] < sep[i0]) i0 = c;
+        int i1 = -1; real bd = -1;
+        for (int c = 0; c < m; c++) {
+            if (c == i0) continue;
+            real du = pts[c][0] - pts[i0][0], dv = pts[c][1] - pts[i0][1];
+            real dd = du * du + dv * dv;
+            if (dd > bd) { bd = dd; i1 = c; }
+        }
+        int i2 = -1, i3 = -1; real amax = 0, amin = 0;
+        for (int c = 0; c < m; c++) {
+            if (c == i0 || c == i1) continue;
+            real ar = (pts[i1][0] - pts[i0][0]) * (pts[c][1] - pts[i0][1]) - (pts[i1][1] - pts[i0][1]) * (pts[c][0] - pts[i0][0]);
+            if (ar > amax) { amax = ar; i2 = c; }
+            if (ar < amin) { amin = ar; i3 = c; }
+        }
+        sel[ns++] = i0; sel[ns++] = i1;
+        if (i2 >= 0) sel[ns++] = i2;
+        if (i3 >= 0) sel[ns++] = i3;
+    }
+    for (int c = 0; c < ns; c++) {
+        int s = sel[c];
+        real pin[3], pref[3];
+        v3cpy(pin, cr);
+        v3axpy(pin, pts[s][0], Rr[ru]);
+        v3axpy(pin, pts[s][1], Rr[rv]);
+        v3cpy(pref, pin);
+        v3axpy(pin, pts[s][2], nr);
+        v3axpy(pref, hr[ax], nr);
+        if (refA) { v3cpy(out[c].pa, pref); v3cpy(out[c].pb, pin); v3set(out[c].n, -nr[0], -nr[1], -nr[2]); }
+        else { v3cpy(out[c].pa, pin); v3cpy(out[c].pb, pref); v3cpy(out[c].n, nr); }
+        out[c].dist = sep[s];
+    }
+    return ns;
+}
+
+int pmgo_box_box(const double ca[3], const double Ra[9], const double ha[3], const double cb[3], const double Rb[9],
+                 const double hb[3], double margin, double* out)
+{
+    real a[3], b[3], RA[9], RB[9], HA[3], HB[3];
+    for (int i = 0; i < 3; i++) { a[i] = (real)ca[i]; b[i] = (real)cb[i]; HA[i] = (real)ha[i]; HB[i] = (real)hb[i]; }
+    for (int i = 0; i < 9; i++) { RA[i] = (real)Ra[i]; RB[i] = (real)Rb[i]; }
+    CPoint cp[4];
+    int n = box_box(a, RA, HA, b, RB, HB, (real)margin, cp);
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) { out[10 * i + k] = cp[i].pa[k]; out[10 * i + 3 + k] = cp[i].pb[k]; out[10 * i + 6 + k] = cp[i].n[k]; }
+        out[10 * i + 9] = cp[i].dist;
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* world state                                                          */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    real pos[3], quat[4], vel[3], omg[3];
+} Block;
+
+typedef struct {
+    real q[NJ], qd[NJ];
+    real motor_target[NJ];
+    real motor_maximp[NJ];
+    real ee_target[3];
+    real joint_target[7];
+    real rest_pose[7];
+    real grip_target;
+    int arm_enabled;
+    int elapsed, reset_count;
+    real goal[16];
+    int order[NBMAX];
+    real base_target[3];
+    Block blk[NBMAX];
+    mt19937 rng;
+} World;
+
+struct pmgo_env {
+    pmg_config cfg;
+    pmg_dims dims;
+    int nb;              /* dynamic objects */
+    int grasping, has_obj, in_air, start_on_table;
+    real tip_init[3], obj_lo[3], obj_hi[3], tgt_lo[3], tgt_hi[3];
+    real ee_lo[3], ee_hi[3];
+    real table_c[3], table_h[3], table_mu;
+    real obj_z;
+    World* w;
+    int nthreads;
+    char err[256];
+};
+static char g_create_err[256];
+
+/* body ids in contacts: 0..NBMAX-1 blocks, 100+L robot Bullet link L, -1 static */
+#define BODY_STATIC (-1)
+#define BODY_ROBOT(L) (100 + (L))
+
+typedef struct {
+    int a, b;
+    real pa[3], pb[3], n[3], dist, mu;
+} Contact;
+
+typedef struct {
+    real Jr[NJ];          /* robot part of the row Jacobian */
+    real dvr[NJ];         /* M^-1 Jr^T */
+    int has_robot;
+    int blk[2];           /* block ids (-1 none) */
+    real Jl[2][3], Ja[2][3];
+    real dl[2][3], da[2][3];
+    real diag_inv, rhs, lo, hi, applied, mu;
+    int fric_of;          /* index of the normal row for friction rows */
+} Row;
+
+static void block_R(const Block* b, real* R) { quat_to_R(b->quat, R); }
+
+static void block_inv_inertia_apply(const Block* b, const real* t, real* out)
+{
+    real R[9], l[3];
+    block_R(b, R);
+    m3tv(l, R, t);
+    for (int a = 0; a < 3; a++) l[a] /= (real)BLOCK_INERTIA[a];
+    m3v(out, R, l);
+}
+
+/* fill a constraint row between body a (+) and body b (-) along direction n at points pa/pb */
+static void row_setup(const pmgo_env* e, const World* w, const Kin* k, const AbaCache* ac, Row* r, int a, int b,
+                      const real* pa, const real* pb, const real* n, real* rel_vel_out)
+{
+    (void)e;
+    memset(r, 0, sizeof(*r));
+    r->blk[0] = r->blk[1] = -1;
+    real denom = 0, rel = 0;
+    int bodies[2] = {a, b};
+    const real* pts[2] = {pa, pb};
+    for (int s = 0; s < 2; s++) {
+        real sg = s == 0 ? (real)1 : (real)-1;
+        int id = bodies[s];
+        if (id == BODY_STATIC) continue;
+        if (id >= 100) {
+            real J[NJ], nn[3] = {sg * n[0], sg * n[1], sg * n[2]};
+            point_jacobian(k, id - 100, pts[s], nn, J);
+            for (int d = 0; d < NJ; d++) r->Jr[d] += J[d];
+            r->has_robot = 1;
+        } else {
+            const Block* bl = &w->blk[id];
+            real rp[3], rxn[3];
+            v3sub(rp, pts[s], bl->pos);
+            v3cross(rxn, rp, n);
+            for (int c = 0; c < 3; c++) { r->Jl[s][c] = sg * n[c]; r->Ja[s][c] = sg * rxn[c]; }
+            r->blk[s] = id;
+            for (int c = 0; c < 3; c++) r->dl[s][c] = r->Jl[s][c] / (real)PMG_BLOCK_MASS;
+            block_inv_inertia_apply(bl, r->Ja[s], r->da[s]);
+            denom += v3dot(r->Jl[s], r->dl[s]) + v3dot(r->Ja[s], r->da[s]);
+            rel += v3dot(r->Jl[s], bl->vel) + v3dot(r->Ja[s], bl->omg);
+        }
+    }
+    if (r->has_robot) {
+        aba_response(k, ac, r->Jr, r->dvr);
+        for (int d = 0; d < NJ; d++) { denom += r->Jr[d] * r->dvr[d]; rel += r->Jr[d] * w->qd[d]; }
+    }
+    r->diag_inv = denom > (real)1.1920929e-07 ? 1 / denom : 0; /* [BULLET-PRIOR] d > SIMD_EPSILON */
+    *rel_vel_out = rel;
+}
+
+/* ------------------------------------------------------------------ */
+/* one 2 ms substep: collide, forward dynamics, PGS, integrate          */
+/* [BULLET-PRIOR] btMultiBodyDynamicsWorld::internalSingleStepSimulation  */
+/* ------------------------------------------------------------------ */
+static void robot_box_pose(const Kin* k, int L, real* c, real* R)
+{
+    v3cpy(c, k->p[L]);
+    memcpy(R, k->R[L], 9 * sizeof(real));
+}
+
+static int collide(const pmgo_env* e, const World* w, const Kin* k, Contact* out)
+{
+    int nc = 0;
+    CPoint cp[4];
+    real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    real fh[3] = {(real)FINGER_HALF[0], (real)FINGER_HALF[1], (real)FINGER_HALF[2]};
+    real bh[3] = {(real)BLOCK_HALF[0], (real)BLOCK_HALF[1], (real)BLOCK_HALF[2]};
+    real Rb[NBMAX][9];
+    for (int b = 0; b < e->nb; b++) block_R(&w->blk[b], Rb[b]);
+#define EMIT(A, B, MU)                                                                  \
+    for (int c_ = 0; c_ < n_ && nc < MAX_CONTACTS; c_++) {                              \
+        Contact* o = &out[nc++];                                                        \
+        o->a = (A); o->b = (B); o->mu = (MU); o->dist = cp[c_].dist;                    \
+        v3cpy(o->pa, cp[c_].pa); v3cpy(o->pb, cp[c_].pb); v3cpy(o->n, cp[c_].n);        \
+    }
+    /* block (A) x table (B) */
+    for (int b = 0; b < e->nb; b++) {
+        int n_ = box_box(w->blk[b].pos, Rb[b], bh, e->table_c, I3, e->table_h, CONTACT_MARGIN, cp);
+        EMIT(b, BODY_STATIC, (real)PMG_BLOCK_FRICTION * e->table_mu)
+    }
+    /* block x block */
+    for (int b = 0; b < e->nb; b++)
+        for (int c = b + 1; c < e->nb; c++) {
+            real dd[3];
+            v3sub(dd, w->blk[b].pos, w->blk[c].pos);
+            if (v3dot(dd, dd) > (real)(0.06 * 0.06)) continue; /* bounding spheres: 2*sqrt(3)*0.015+margin < 0.06 */
+            int n_ = box_box(w->blk[b].pos, Rb[b], bh, w->blk[c].pos, Rb[c], bh, CONTACT_MARGIN, cp);
+            EMIT(b, c, (real)(PMG_BLOCK_FRICTION * PMG_BLOCK_FRICTION))
+        }
+    /* fingers (A) x blocks (B), fingers x table */
+    static const int FL[2] = {PMG_BL_FINGER1, PMG_BL_FINGER2};
+    for (int f = 0; f < 2; f++) {
+        real fc[3], fR[9];
+        robot_box_pose(k, FL[f], fc, fR);
+        for (int b = 0; b < e->nb; b++) {
+            real dd[3];
+            v3sub(dd, fc, w->blk[b].pos);
+            if (v3dot(dd, dd) > (real)(0.075 * 0.075)) continue; /* 0.0431 + 0.026 + margin */
+            int n_ = box_box(fc, fR, fh, w->blk[b].pos, Rb[b], bh, CONTACT_MARGIN, cp);
+            EMIT(BODY_ROBOT(FL[f]), b, (real)(PMG_FINGER_FRICTION * PMG_BLOCK_FRICTION))
+        }
+        if (fc[2] - (real)0.0431 < e->table_c[2] + e->table_h[2] + CONTACT_MARGIN) {
+            int n_ = box_box(fc, fR, fh, e->table_c, I3, e->table_h, CONTACT_MARGIN, cp);
+            EMIT(BODY_ROBOT(FL[f]), BODY_STATIC, (real)PMG_FINGER_FRICTION * e->table_mu)
+        }
+    }
+#undef EMIT
+    return nc;
+}
+
+/* [BULLET-PRIOR] btPlaneSpace1 */
+static void plane_space(const real* n, real* p, real* q)
+{
+    if (RFABS(n[2]) > (real)0.7071067811865475244008443621048490) {
+        real a = n[1] * n[1] + n[2] * n[2];
+        real k = 1 / RSQRT(a);
+        v3set(p, 0, -n[2] * k, n[1] * k);
+        v3set(q, a * k, -n[0] * p[2], n[0] * p[1]);
+    } else {
+        real a = n[0] * n[0] + n[1] * n[1];
+        real k = 1 / RSQRT(a);
+        v3set(p, -n[1] * k, n[0] * k, 0);
+        v3set(q, -n[2] * p[1], n[2] * p[0], a * k);
+    }
+}
+
+static real row_solve(Row* r, real* dqd, real (*dbl)[3], real (*dba)[3])
+{
+    real dv = 0;
+    if (r->has_robot)
+        for (int d = 0; d < NJ; d++) dv += r->Jr[d] * dqd[d];
+    for (int s = 0; s < 2; s++)
+        if (r->blk[s] >= 0) dv += v3dot(r->Jl[s], dbl[r->blk[s]]) + v3dot(r->Ja[s], dba[r->blk[s]]);
+    real delta = r->rhs - dv * r->diag_inv;
+    real sum = r->applied + delta;
+    if (sum < r->lo) { delta = r->lo - r->applied; r->applied = r->lo; }
+    else if (sum > r->hi) { delta = r->hi - r->applied; r->applied = r->hi; }
+    else r->applied = sum;
+    if (r->has_robot)
+        for (int d = 0; d < NJ; d++) dqd[d] += r->dvr[d] * delta;
+    for (int s = 0; s < 2; s++)
+        if (r->blk[s] >= 0) { v3axpy(dbl[r->blk[s]], delta, r->dl[s]); v3axpy(dba[r->blk[s]], delta, r->da[s]); }
+    return r->diag_inv != 0 ? delta / r->diag_inv : 0;
+}
+
+static void substep(const pmgo_env* e, World* w, const real* tau)
+{
+    const real dt = SUBSTEP_DT;
+    Kin k;
+    AbaCache ac;
+    kinematics(w->q, &k);
+    /* 1. collision detection at the current poses */
+    Contact con[MAX_CONTACTS];
+    int nc = collide(e, w, &k, con);
+    /* 2. unconstrained velocity update */
+    real qdd[NJ];
+    aba(&k, w->qd, tau, qdd, &ac);
+    for (int d = 0; d < NJ; d++) w->qd[d] += dt * qdd[d];
+    for (int b = 0; b < e->nb; b++) {
+        Block* bl = &w->blk[b];
+        /* floating base with zero links: gravity, link damping, gyroscopic term */
+        real kl = LINK_DAMPING * (1 + v3norm(bl->vel)), ka = LINK_DAMPING * (1 + v3norm(bl->omg));
+        real R[9], wl[3], Iw[3], gy[3], tq[3], al[3];
+        block_R(bl, R);
+        m3tv(wl, R, bl->omg);
+        for (int a = 0; a < 3; a++) Iw[a] = (real)BLOCK_INERTIA[a] * wl[a];
+        v3cross(gy, wl, Iw);
+        for (int a = 0; a < 3; a++) tq[a] = (-Iw[a] * ka - gy[a]) / (real)BLOCK_INERTIA[a];
+        m3v(al, R, tq);
+        for (int a = 0; a < 3; a++) {
+            bl->vel[a] += dt * (-bl->vel[a] * kl + (a == 2 ? -GRAVITY : 0));
+            bl->omg[a] += dt * al[a];
+        }
+    }
+    /* 3. constraint rows */
+    Row nonc[2 * NJ];
+    int nn = 0;
+    for (int oi = 0; oi < 18; oi++) {
+        int ci = ROW_ORDER[oi];
+        int d = ci % NJ;
+        Row* r = &nonc[nn];
+        if (ci >= NJ) {
+            /* [BULLET-PRIOR] btMultiBodyJointMotor::createConstraintRows (erp 1, rhsClamp inf) */
+            if (w->motor_maximp[d] <= 0) continue;
+            memset(r, 0, sizeof(*r));
+            r->blk[0] = r->blk[1] = -1;
+            r->has_robot = 1;
+            r->Jr[d] = 1;
+            aba_response(&k, &ac, r->Jr, r->dvr);
+            real den = r->dvr[d];
+            r->diag_inv = den > (real)1.1920929e-07 ? 1 / den : 0;
+            real kd = ARM_KD, kp = ARM_KP;
+            real target_v = kp * (w->motor_target[d] - w->q[d]) / dt + w->qd[d] + kd * (0 - w->qd[d]);
+            r->rhs = (target_v - w->qd[d]) * r->diag_inv;
+            r->lo = -w->motor_maximp[d];
+            r->hi = w->motor_maximp[d];
+            nn++;
+        } else {
+            /* [BULLET-PRIOR] btMultiBodyJointLimitConstraint::createConstraintRows */
+            for (int side = 0; side < 2; side++) {
+                real pen = side == 0 ? w->q[d] - (real)JLO[d] : (real)JHI[d] - w->q[d];
+                if (pen > 0) continue;
+                r = &nonc[nn];
+                memset(r, 0, sizeof(*r));
+                r->blk[0] = r->blk[1] = -1;
+                r->has_robot = 1;
+                r->Jr[d] = side == 0 ? (real)1 : (real)-1;
+                aba_response(&k, &ac, r->Jr, r->dvr);
+                real den = r->Jr[d] * r->dvr[d];
+                r->diag_inv = den > (real)1.1920929e-07 ? 1 / den : 0;
+                real rel = r->Jr[d] * w->qd[d];
+                r->rhs = (-pen * JOINT_ERP / dt - rel) * r->diag_inv;
+                r->lo = 0;
+                r->hi = LIMIT_MAX_IMPULSE;
+                nn++;
+            }
+        }
+    }
+    Row nrm[MAX_CONTACTS], fri[2 * MAX_CONTACTS];
+    for (int c = 0; c < nc; c++) {
+        /* [BULLET-PRIOR] btMultiBodyConstraintSolver::setupMultiBodyContactConstraint */
+        Contact* cp = &con[c];
+        real rel;
+        Row* r = &nrm[c];
+        row_setup(e, w, &k, &ac, r, cp->a, cp->b, cp->pa, cp->pb, cp->n, &rel);
+        real dist = cp->dist + LINEAR_SLOP;
+        real pos_err = 0, vel_err = -rel;
+        if (dist > 0) vel_err -= dist / dt;
+        else pos_err = -dist * CONTACT_ERP / dt;
+        r->rhs = (pos_err + vel_err) * r->diag_inv;
+        r->lo = 0;
+        r->hi = (real)1e10;
+        real t1[3], t2[3];
+        plane_space(cp->n, t1, t2);
+        real* tt[2] = {t1, t2};
+        for (int f = 0; f < 2; f++) {
+            Row* fr = &fri[2 * c + f];
+            row_setup(e, w, &k, &ac, fr, cp->a, cp->b, cp->pa, cp->pb, tt[f], &rel);
+            fr->rhs = -rel * fr->diag_inv;
+            fr->mu = cp->mu;
+            fr->fric_of = c;
+            fr->lo = fr->hi = 0;
+        }
+    }
+    /* 4. projected Gauss-Seidel, [BULLET-PRIOR] btMultiBodyConstraintSolver::solveSingleIteration */
+    real dqd[NJ], dbl[NBMAX][3], dba[NBMAX][3];
+    memset(dqd, 0, sizeof(dqd));
+    memset(dbl, 0, sizeof(dbl));
+    memset(dba, 0, sizeof(dba));
+    for (int it = 0; it < SOLVER_ITERS; it++) {
+        real resid = 0;
+        for (int j = 0; j < nn; j++) {
+            int idx = (it & 1) ? j : nn - 1 - j;
+            real dv = row_solve(&nonc[idx], dqd, dbl, dba);
+            resid = dv * dv > resid ? dv * dv : resid;
+        }
+        for (int c = 0; c < nc; c++) {
+            real dv = row_solve(&nrm[c], dqd, dbl, dba);
+            resid = dv * dv > resid ? dv * dv : resid;
+        }
+        for (int c = 0; c < 2 * nc; c++) {
+            Row* fr = &fri[c];
+            real tot = nrm[fr->fric_of].applied;
+            if (tot > 0) {
+                fr->lo = -fr->mu * tot;
+                fr->hi = fr->mu * tot;
+                real dv = row_solve(fr, dqd, dbl, dba);
+                resid = dv * dv > resid ? dv * dv : resid;
+            }
+        }
+        if (resid <= RESIDUAL_THRESHOLD) break;
+    }
+    for (int d = 0; d < NJ; d++) w->qd[d] += dqd[d];
+    /* 5. integrate positions */
+    for (int d = 0; d < NJ; d++) w->q[d] += dt * w->qd[d];
+    for (int b = 0; b < e->nb; b++) {
+        Block* bl = &w->blk[b];
+        for (int a = 0; a < 3; a++) { bl->vel[a] += dbl[b][a]; bl->omg[a] += dba[b][a]; }
+        for (int a = 0; a < 3; a++) bl->pos[a] += dt * bl->vel[a];
+        /* quat <- exp(omega dt) * quat  ([BULLET-PRIOR] btMultiBody::stepPositionsMultiDof) */
+        real ang = v3norm(bl->omg) * dt;
+        real dq[4] = {0, 0, 0, 1};
+        if (ang > (real)1e-12) {
+            real s = RSIN(ang / 2) / (ang / dt);
+            dq[0] = bl->omg[0] * s; dq[1] = bl->omg[1] * s; dq[2] = bl->omg[2] * s; dq[3] = RCOS(ang / 2);
+        }
+        real nq[4];
+        quat_mul(nq, dq, bl->quat);
+        real nn2 = RSQRT(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
+        for (int a = 0; a < 4; a++) bl->quat[a] = nq[a] / nn2;
+    }
+}
+
+/* stepSimulation(): 20 substeps with forces latched at entry.
+ * [BULLET-PRIOR] PhysicsServerCommandProcessor applies URDF joint damping once per
+ * stepSimulation as a joint torque (-damping*qd) that persists over the substeps. */
+static void step_simulation(const pmgo_env* e, World* w)
+{
+    real tau[NJ];
+    for (int d = 0; d < NJ; d++) tau[d] = -(real)JDAMP[d] * w->qd[d];
+    for (int s = 0; s < SUBSTEPS; s++) substep(e, w, tau);
+}
+
+/* ------------------------------------------------------------------ */
+/* environment logic                                                    */
+/* ------------------------------------------------------------------ */
+static void env_constants(pmgo_env* e)
+{
+    const pmg_config* c = &e->cfg;
+    int t = c->task;
+    e->grasping = (t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
+    e->has_obj = (t != PMG_TASK_REACH);
+    e->in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
+    e->start_on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE);
+    e->nb = t == PMG_TASK_REACH ? 0 : (t == PMG_TASK_BLOCK_STACK ? c->num_block : 1);
+    real obj_range = t == PMG_TASK_SLIDE ? (real)0.1 : (real)0.15, tgt_range = t == PMG_TASK_SLIDE ? (real)0.2 : (real)0.15;
+    /* kuka.py:35-51 */
+    v3set(e->tip_init, (real)-0.52, 0, (real)0.25);
+    if (e->start_on_table) e->tip_init[2] = (real)0.175 + (real)0.001;
+    v3set(e->ee_hi, (real)-0.37, (real)0.20, (real)0.55);
+    v3set(e->ee_lo, (real)-0.67, (real)-0.20, (real)0.175);
+    for (int a = 0; a < 3; a++) {
+        e->obj_lo[a] = e->tip_init[a] - obj_range; e->obj_hi[a] = e->tip_init[a] + obj_range;
+        e->tgt_lo[a] = e->tip_init[a] - tgt_range; e->tgt_hi[a] = e->tip_init[a] + tgt_range;
+    }
+    e->obj_lo[0] += (real)0.03; e->obj_hi[0] -= (real)0.03;
+    e->tgt_lo[0] += (real)0.03; e->tgt_hi[0] -= (real)0.03;
+    e->tgt_lo[2] = e->ee_lo[2];
+    v3set(e->table_c, (real)-0.52, 0, (real)0.08); /* kuka_single_step_base_env.py:49 */
+    for (int a = 0; a < 3; a++) e->table_h[a] = (real)TABLE_HALF[a];
+    e->table_mu = (real)PMG_TABLE_FRICTION;
+    e->obj_z = (real)0.175;
+    if (t == PMG_TASK_SLIDE) { /* kuka_single_step_base_env.py:53-56,66-69 */
+        e->tgt_lo[0] -= (real)0.4; e->tgt_hi[0] -= (real)0.4;
+        e->table_c[0] = (real)-0.70;
+        static const double LT[3] = PMG_LONG_TABLE_HALF;
+        for (int a = 0; a < 3; a++) e->table_h[a] = (real)LT[a];
+        e->table_mu = (real)PMG_LONG_TABLE_FRICTION;
+        e->obj_z = (real)0.170;
+    }
+}
+
+static void tip_state(const World* w, const Kin* k, real* pos, real* vel, real* omg)
+{
+    v3cpy(pos, k->p[PMG_BL_TIP]);
+    point_velocity(k, w->qd, PMG_BL_TIP, pos, vel, omg);
+}
+
+/* robot reset, kuka.py:120-165 */
+static void robot_reset(const pmgo_env* e, World* w)
+{
+    real tq[4] = {(real)TOOL_QUAT[0], (real)TOOL_QUAT[1], (real)TOOL_QUAT[2], (real)TOOL_QUAT[3]};
+    for (int d = 0; d < 7; d++) { w->q[d] = w->rest_pose[d]; w->qd[d] = 0; w->motor_maximp[d] = 0; } /* :158 + robot_bases.py:230-238 */
+    real qo[NJ];
+    ik_solve(w->q, e->tip_init, tq, IK_MAX_ITER, IK_THRESHOLD, qo);                                    /* :159 */
+    for (int d = 0; d < 7; d++) { w->rest_pose[d] = qo[d]; w->q[d] = qo[d]; w->qd[d] = 0; }          /* :160 */
+    for (int d = 7; d < 9; d++) { w->q[d] = FINGER_LIMIT; w->qd[d] = 0; }                             /* :161 */
+    w->grip_target = FINGER_LIMIT;                                                                     /* :162 */
+    for (int d = 7; d < 9; d++) { w->motor_target[d] = FINGER_LIMIT; w->motor_maximp[d] = FINGER_FORCE * PHYSICS_DT; }
+    w->arm_enabled = 0;
+    Kin k;
+    kinematics(w->q, &k);
+    v3cpy(w->ee_target, k.p[PMG_BL_TIP]);                                                              /* :163 */
+    for (int d = 0; d < 7; d++) w->joint_target[d] = w->q[d];                                          /* :165 */
+}
+
+static void set_block(Block* b, real x, real y, real z)
+{
+    v3set(b->pos, x, y, z);
+    b->quat[0] = b->quat[1] = b->quat[2] = 0; b->quat[3] = 1;
+    v3set(b->vel, 0, 0, 0);
+    v3set(b->omg, 0, 0, 0);
+}
+
+/* single-step task reset: kuka_single_step_base_env.py:76-148 */
+static void task_reset_single(const pmgo_env* e, World* w)
+{
+    double center[3] = {e->tip_init[0], e->tip_init[1], e->tip_init[2]};
+    if (e->has_obj) {
+        double oxy[2] = {e->tip_init[0], e->tip_init[1]};
+        while (hypot(oxy[0] - e->tip_init[0], oxy[1] - e->tip_init[1]) < 0.1) {      /* :108-111 */
+            oxy[0] = mt_uniform(&w->rng, e->obj_lo[0], e->obj_hi[0]);
+            oxy[1] = mt_uniform(&w->rng, e->obj_lo[1], e->obj_hi[1]);
+        }
+        set_block(&w->blk[0], (real)oxy[0], (real)oxy[1], e->obj_z);
+        center[0] = oxy[0]; center[1] = oxy[1]; center[2] = e->obj_z;
+    }
+    double g[3];
+    for (;;) {                                                                          /* :132-136 */
+        for (int a = 0; a < 3; a++) g[a] = mt_uniform(&w->rng, e->tgt_lo[a], e->tgt_hi[a]);
+        double dx = g[0] - center[0], dy = g[1] - center[1], dz = g[2] - center[2];
+        if (sqrt(dx * dx + dy * dy + dz * dz) > 0.1) break;
+    }
+    if (!e->in_air) g[2] = e->obj_z;                                                    /* :138-139 */
+    else if (e->grasping) {
+        if (mt_uniform(&w->rng, 0, 1) >= 0.5) g[2] = e->obj_z;                          /* :140-143 */
+    }
+    for (int a = 0; a < 3; a++) w->goal[a] = (real)g[a];
+}
+
+/* block-stack reset: kuka_multi_step_base_env.py:221-250 + kuka_multi_step_envs.py:34-87 */
+static void stack_goal_from_order(const pmgo_env* e, World* w)
+{
+    for (int s = 0; s < e->nb; s++) {
+        int b = w->order[s];
+        w->goal[3 * b] = w->base_target[0];
+        w->goal[3 * b + 1] = w->base_target[1];
+        w->goal[3 * b + 2] = (real)0.175 + (real)0.03 * (real)s;
+    }
+}
+static void task_reset_stack(const pmgo_env* e, World* w)
+{
+    double bp[NBMAX][2];
+    for (int b = 0; b < e->nb; b++) {
+        for (;;) {
+            double x = mt_uniform(&w->rng, e->obj_lo[0], e->obj_hi[0]);
+            double y = mt_uniform(&w->rng, e->obj_lo[1], e->obj_hi[1]);
+            int ok = 1;
+            for (int c = 0; c < b; c++)
+                if (!(hypot(x - bp[c][0], y - bp[c][1]) > 0.06)) ok = 0;
+            if (!(hypot(x - e->tip_init[0], y - e->tip_init[1]) > 0.06)) ok = 0;
+            if (ok) { bp[b][0] = x; bp[b][1] = y; break; }
+        }
+    }
+    for (int b = 0; b < e->nb; b++) set_block(&w->blk[b], (real)bp[b][0], (real)bp[b][1], (real)0.175);
+    for (int b = 0; b < e->nb; b++) w->order[b] = b;
+    if (e->cfg.random_order)
+        for (int i = e->nb - 1; i >= 1; i--) {
+            uint32_t j = mt_interval(&w->rng, (uint32_t)i);
+            int t = w->order[i]; w->order[i] = w->order[j]; w->order[j] = t;
+        }
+    for (;;) {
+        double x = mt_uniform(&w->rng, e->tgt_lo[0], e->tgt_hi[0]);
+        double y = mt_uniform(&w->rng, e->tgt_lo[1], e->tgt_hi[1]);
+        int ok = 1;
+        for (int c = 0; c < e->nb; c++)
+            if (!(hypot(x - bp[c][0], y - bp[c][1]) > 0.08)) ok = 0;
+        if (ok) { v3set(w->base_target, (real)x, (real)y, (real)0.175); break; }
+    }
+    stack_goal_from_order(e, w);
+}
+
+static void env_reset_one(const pmgo_env* e, World* w)
+{
+    robot_reset(e, w);
+    if (e->cfg.task == PMG_TASK_BLOCK_STACK) task_reset_stack(e, w);
+    else task_reset_single(e, w);
+    w->elapsed = 0;
+    w->reset_count++;
+}
+
+/* observation assembly.  single: kuka_single_step_base_env.py:193-221; stack:
+ * kuka_multi_step_base_env.py:255-336; robot state: kuka.py:227-256 */
+static void env_obs(const pmgo_env* e, const World* w, float* obs, float* pol, float* ag, float* dg)
+{
+    Kin k;
+    kinematics(w->q, &k);
+    real tip[3], tv[3], tw[3];
+    tip_state(w, &k, tip, tv, tw);
+    real closeness = 0, fvel = 0;
+    if (e->grasping) {
+        real d[3];
+        v3sub(d, k.p[PMG_BL_TAB1], k.p[PMG_BL_TAB2]);
+        closeness = v3norm(d);
+        real vb[3], vt[3], tmp[3];
+        point_velocity(&k, w->qd, PMG_BL_GBASE, k.p[PMG_BL_GBASE], vb, tmp);
+        point_velocity(&k, w->qd, PMG_BL_TAB1, k.p[PMG_BL_TAB1], vt, tmp);
+        fvel = vb[1] - vt[1];
+    }
+    int jo = e->cfg.joint_control ? 7 : 0;
+    int G = e->dims.goal_dim;
+    double o[160], p[64];
+    int no = 0, np = 0;
+    if (jo) for (int d = 0; d < 7; d++) { o[no++] = w->q[d]; p[np++] = w->q[d]; }
+    if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
+        for (int a = 0; a < 3; a++) { o[no++] = tip[a]; p[np++] = tip[a]; }
+        o[no++] = closeness; p[np++] = closeness;
+        for (int a = 0; a < 3; a++) o[no++] = tv[a];
+        o[no++] = fvel;
+        for (int b = 0; b < e->nb; b++) {
+            const Block* bl = &w->blk[b];
+            for (int a = 0; a < 3; a++) o[no++] = bl->pos[a];
+            for (int a = 0; a < 3; a++) { o[no++] = tip[a] - bl->pos[a]; p[np++] = tip[a] - bl->pos[a]; }
+            for (int a = 0; a < 4; a++) o[no++] = bl->quat[a];
+            for (int a = 0; a < 3; a++) o[no++] = tv[a] - bl->vel[a];
+            for (int a = 0; a < 3; a++) o[no++] = tw[a] - bl->omg[a];
+            if (ag) for (int a = 0; a < 3; a++) ag[3 * b + a] = (float)bl->pos[a];
+        }
+        for (int i = 0; i < no; i++) o[i] = o[i] < -5 ? -5 : (o[i] > 5 ? 5 : o[i]);  /* :306-307 */
+        for (int i = 0; i < np; i++) p[i] = p[i] < -5 ? -5 : (p[i] > 5 ? 5 : p[i]);
+    } else if (e->has_obj) {
+        const Block* bl = &w->blk[0];
+        for (int a = 0; a < 3; a++) o[no++] = tip[a];
+        for (int a = 0; a < 3; a++) o[no++] = bl->pos[a];
+        o[no++] = closeness;
+        for (int a = 0; a < 3; a++) o[no++] = tip[a] - bl->pos[a];
+        for (int a = 0; a < 3; a++) o[no++] = tv[a];
+        o[no++] = fvel;
+        for (int a = 0; a < 3; a++) o[no++] = tv[a] - bl->vel[a];
+        for (int a = 0; a < 3; a++) o[no++] = tw[a] - bl->omg[a];
+        for (int a = 0; a < 3; a++) p[np++] = tip[a];
+        p[np++] = closeness;
+        for (int a = 0; a < 3; a++) p[np++] = tip[a] - bl->pos[a];
+        if (ag) for (int a = 0; a < 3; a++) ag[a] = (float)bl->pos[a];
+    } else {
+        for (int a = 0; a < 3; a++) { o[no++] = tip[a]; p[np++] = tip[a]; }
+        if (ag) for (int a = 0; a < 3; a++) ag[a] = (float)tip[a];
+    }
+    if (obs) for (int i = 0; i < no; i++) obs[i] = (float)o[i];
+    if (pol) for (int i = 0; i < np; i++) pol[i] = (float)p[i];
+    if (dg) for (int i = 0; i < G; i++) dg[i] = (float)w->goal[i];
+}
+
+/* reward: kuka_single_step_base_env.py:237-244 */
+static void reward_f64(const pmgo_env* e, const double* ag, const double* dg, int G, float* r, uint8_t* ok)
+{
+    double s = 0;
+    for (int i = 0; i < G; i++) s += (ag[i] - dg[i]) * (ag[i] - dg[i]);
+    double d = sqrt(s);
+    int not_achieved = d > (double)e->cfg.distance_threshold;
+    if (e->cfg.binary_reward) *r = -(float)not_achieved;
+    else *r = (float)(-d);
+    *ok = (uint8_t)!not_achieved;
+}
+
+/* apply_action: kuka.py:167-225 */
+static void env_step_one(const pmgo_env* e, World* w, const float* a)
+{
+    int A = e->dims.action_dim;
+    real tq[4] = {(real)TOOL_QUAT[0], (real)TOOL_QUAT[1], (real)TOOL_QUAT[2], (real)TOOL_QUAT[3]};
+    if (e->grasping) {
+        w->grip_target = (real)(((double)a[A - 1] + 1.0) * (0.035 / 2));               /* :171 */
+        for (int d = 7; d < 9; d++) { w->motor_target[d] = w->grip_target; w->motor_maximp[d] = FINGER_FORCE * PHYSICS_DT; }
+    }
+    real poses[NJ];
+    if (e->cfg.joint_control) {
+        for (int d = 0; d < 7; d++) { w->joint_target[d] = (real)(float)(a[d] * 0.05f) + w->joint_target[d]; poses[d] = w->joint_target[d]; } /* :205 */
+    } else {
+        for (int c = 0; c < 3; c++) {
+            real t = w->ee_target[c] + (real)(float)(a[c] * 0.01f);                     /* :209 (float32 product) */
+            w->ee_target[c] = t < e->ee_lo[c] ? e->ee_lo[c] : (t > e->ee_hi[c] ? e->ee_hi[c] : t); /* :210-212 */
+        }
+        ik_solve(w->q, w->ee_target, tq, IK_MAX_ITER, IK_THRESHOLD, poses);            /* :214 */
+    }
+    for (int d = 0; d < 7; d++) { w->motor_target[d] = poses[d]; w->motor_maximp[d] = ARM_FORCE * PHYSICS_DT; } /* :222, :282-290 */
+    w->arm_enabled = 1;
+    for (int s = 0; s < SIM_STEPS; s++) step_simulation(e, w);                         /* :223-225 */
+    w->elapsed++;
+}
+
+/* ------------------------------------------------------------------ */
+/* C ABI                                                                */
+/* ------------------------------------------------------------------ */
+static int fill_dims(const pmg_config* c, pmg_dims* d)
+{
+    memset(d, 0, sizeof(*d));
+    int jo = c->joint_control ? 7 : 0;
+    d->num_envs = c->num_envs;
+    switch (c->task) {
+    case PMG_TASK_REACH:
+        d->action_dim = jo ? 7 : 3; d->observation_dim = 3 + jo; d->policy_state_dim = 3 + jo; d->goal_dim = 3; break;
+    case PMG_TASK_PUSH:
+    case PMG_TASK_SLIDE:
+        d->action_dim = jo ? 7 : 3; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
+    case PMG_TASK_PICK_AND_PLACE:
+        d->action_dim = jo ? 8 : 4; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
+    case PMG_TASK_BLOCK_STACK:
+        if (c->num_block < 1 || c->num_block > NBMAX) return -1;
+        d->action_dim = jo ? 8 : 4; d->observation_dim = 8 + 16 * c->num_block + jo;
+        d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; break;
+    default: return -1;
+    }
+    int nb = c->task == PMG_TASK_REACH ? 0 : (c->task == PMG_TASK_BLOCK_STACK ? c->num_block : 1);
+    d->state_dim = 64 + 13 * nb;
+    d->packed_dim = d->observation_dim + d->policy_state_dim + 2 * d->goal_dim + 3;
+    return 0;
+}
+
+int pmgo_create(const pmg_config* cfg, pmgo_env** out)
+{
+    if (!cfg || !out || cfg->struct_size != (int32_t)sizeof(pmg_config) || cfg->num_envs < 1) {
+        snprintf(g_create_err, sizeof(g_create_err), "pmgo_create: bad config");
+        return PMG_E_INVALID;
+    }
+    pmgo_env* e = (pmgo_env*)calloc(1, sizeof(pmgo_env));
+    e->cfg = *cfg;
+    if (fill_dims(cfg, &e->dims) != 0 || cfg->task == PMG_TASK_SLIDE) {
+        snprintf(g_create_err, sizeof(g_create_err), "pmgo_create: unsupported task %d / num_block %d", cfg->task, cfg->num_block);
+        free(e);
+        return PMG_E_INVALID;
+    }
+    env_constants(e);
+    e->w = (World*)calloc((size_t)cfg->num_envs, sizeof(World));
+    e->nthreads = 1;
+    for (int i = 0; i < cfg->num_envs; i++) {
+        World* w = &e->w[i];
+        for (int d = 0; d < 7; d++) w->rest_pose[d] = (real)REST_POSE0[d];
+        for (int b = 0; b < NBMAX; b++) set_block(&w->blk[b], 0, 0, -3);
+    }
+    *out = e;
+    pmgo_seed(e, cfg->seed_base, cfg->seed_stride);
+    return PMG_OK;
+}
+void pmgo_destroy(pmgo_env* e)
+{
+    if (!e) return;
+    free(e->w);
+    free(e);
+}
+int pmgo_get_dims(const pmgo_env* e, pmg_dims* out) { *out = e->dims; return PMG_OK; }
+const char* pmgo_last_error(const pmgo_env* e) { return e ? e->err : g_create_err; }
+int pmgo_set_threads(pmgo_env* e, int n) { e->nthreads = n < 1 ? 1 : n; return PMG_OK; }
+
+int pmgo_seed(pmgo_env* e, uint64_t base, uint64_t stride)
+{
+    e->cfg.seed_base = base;
+    e->cfg.seed_stride = stride;
+    for (int i = 0; i < e->cfg.num_envs; i++)
+        gym_seed(&e->w[i].rng, base + stride * (uint64_t)(i + e->cfg.env_index_offset));
+    return PMG_OK;
+}
+
+static void outputs(pmgo_env* e, int i, float* obs, float* pol, float* ag, float* dg)
+{
+    const pmg_dims* d = &e->dims;
+    env_obs(e, &e->w[i], obs ? obs + (size_t)i * d->observation_dim : NULL, pol ? pol + (size_t)i * d->policy_state_dim : NULL,
+            ag ? ag + (size_t)i * d->goal_dim : NULL, dg ? dg + (size_t)i * d->goal_dim : NULL);
+}
+
+int pmgo_reset(pmgo_env* e, const uint8_t* mask, float* obs, float* pol, float* ag, float* dg)
+{
+    int N = e->cfg.num_envs;
+#pragma omp parallel for num_threads(e->nthreads) schedule(static)
+    for (int i = 0; i < N; i++) {
+        if (!mask || mask[i]) env_reset_one(e, &e->w[i]);
+        outputs(e, i, obs, pol, ag, dg);
+    }
+    return PMG_OK;
+}
+
+int pmgo_step(pmgo_env* e, const float* actions, float* obs, float* pol, float* ag, float* dg, float* reward,
+              uint8_t* goal_achieved, uint8_t* done)
+{
+    int N = e->cfg.num_envs;
+    const pmg_dims* dm = &e->dims;
+    for (int i = 0; i < N; i++)
+        if (e->w[i].reset_count == 0) { snprintf(e->err, sizeof(e->err), "pmgo_step: env %d was never reset", i); return PMG_E_STATE; }
+#pragma omp parallel for num_threads(e->nthreads) schedule(static)
+    for (int i = 0; i < N; i++) {
+        World* w = &e->w[i];
+        env_step_one(e, w, actions + (size_t)i * dm->action_dim);
+        float agl[16], dgl[16];
+        env_obs(e, w, obs ? obs + (size_t)i * dm->observation_dim : NULL, pol ? pol + (size_t)i * dm->policy_state_dim : NULL, agl, dgl);
+        /* reward from the double-precision goals (the reference's obs are float64) */
+        double a64[16], d64[16];
+        for (int g = 0; g < dm->goal_dim; g++) d64[g] = w->goal[g];
+        if (e->cfg.task == PMG_TASK_REACH) {
+            Kin k; kinematics(w->q, &k);
+            for (int g = 0; g < 3; g++) a64[g] = k.p[PMG_BL_TIP][g];
+        } else {
+            for (int b = 0; b < e->nb; b++)
+                for (int g = 0; g < 3; g++) a64[3 * b + g] = w->blk[b].pos[g];
+        }
+        float r; uint8_t ok;
+        reward_f64(e, a64, d64, dm->goal_dim, &r, &ok);
+        if (ag) memcpy(ag + (size_t)i * dm->goal_dim, agl, sizeof(float) * dm->goal_dim);
+        if (dg) memcpy(dg + (size_t)i * dm->goal_dim, dgl, sizeof(float) * dm->goal_dim);
+        if (reward) reward[i] = r;
+        if (goal_achieved) goal_achieved[i] = ok;
+        if (done) done[i] = (uint8_t)(w->elapsed >= e->cfg.max_episode_steps);
+    }
+    return PMG_OK;
+}
+
+int pmgo_compute_reward(pmgo_env* e, const float* ag, const float* dg, int64_t batch, float* reward, uint8_t* ok)
+{
+    int G = e->dims.goal_dim;
+    for (int64_t i = 0; i < batch; i++) {
+        double a[16], d[16];
+        for (int g = 0; g < G; g++) { a[g] = ag[i * G + g]; d[g] = dg[i * G + g]; }
+        float r; uint8_t o;
+        reward_f64(e, a, d, G, &r, &o);
+        if (reward) reward[i] = r;
+        if (ok) ok[i] = o;
+    }
+    return PMG_OK;
+}
+
+/* state layout (float32 per env), shared with the product (DESIGN.md "state row"):
+ *  0-8 q | 9-17 qd | 18-20 ee_target | 21-27 joint_target | 28 grip_target | 29 elapsed |
+ *  30 arm_enabled | 31 reset_count | 32-38 rest_pose | 39 - | 40-44 order | 45-47 base_target |
+ *  48-62 desired_goal | 63 - | 64+13b: block b pos3 quat4 vel3 omg3 */
+int pmgo_get_state(pmgo_env* e, float* state)
+{
+    int S = e->dims.state_dim;
+    for (int i = 0; i < e->cfg.num_envs; i++) {
+        const World* w = &e->w[i];
+        float* s = state + (size_t)i * S;
+        memset(s, 0, sizeof(float) * S);
+        for (int d = 0; d < 9; d++) { s[d] = (float)w->q[d]; s[9 + d] = (float)w->qd[d]; }
+        for (int a = 0; a < 3; a++) s[18 + a] = (float)w->ee_target[a];
+        for (int d = 0; d < 7; d++) { s[21 + d] = (float)w->joint_target[d]; s[32 + d] = (float)w->rest_pose[d]; }
+        s[28] = (float)w->grip_target; s[29] = (float)w->elapsed; s[30] = (float)w->arm_enabled; s[31] = (float)w->reset_count;
+        for (int b = 0; b < NBMAX; b++) s[40 + b] = (float)w->order[b];
+        for (int a = 0; a < 3; a++) s[45 + a] = (float)w->base_target[a];
+        for (int g = 0; g < 15; g++) s[48 + g] = (float)w->goal[g];
+        for (int b = 0; b < e->nb; b++) {
+            const Block* bl = &w->blk[b];
+            float* o = s + 64 + 13 * b;
+            for (int a = 0; a < 3; a++) { o[a] = (float)bl->pos[a]; o[7 + a] = (float)bl->vel[a]; o[10 + a] = (float)bl->omg[a]; }
+            for (int a = 0; a < 4; a++) o[3 + a] = (float)bl->quat[a];
+        }
+    }
+    return PMG_OK;
+}
+int pmgo_set_state(pmgo_env* e, const float* state)
+{
+    int S = e->dims.state_dim;
+    for (int i = 0; i < e->cfg.num_envs; i++) {
+        World* w = &e->w[i];
+        const float* s = state + (size_t)i * S;
+        for (int d = 0; d < 9; d++) { w->q[d] = s[d]; w->qd[d] = s[9 + d]; }
+        for (int a = 0; a < 3; a++) w->ee_target[a] = s[18 + a];
+        for (int d = 0; d < 7; d++) { w->joint_target[d] = s[21 + d]; w->rest_pose[d] = s[32 + d]; }
+        w->grip_target = s[28]; w->elapsed = (int)s[29]; w->arm_enabled = (int)s[30]; w->reset_count = (int)s[31];
+        for (int d = 7; d < 9; d++) { w->motor_target[d] = w->grip_target; w->motor_maximp[d] = FINGER_FORCE * PHYSICS_DT; }
+        for (int b = 0; b < NBMAX; b++) w->order[b] = (int)s[40 + b];
+        for (int a = 0; a < 3; a++) w->base_target[a] = s[45 + a];
+        for (int g = 0; g < 15; g++) w->goal[g] = s[48 + g];
+        for (int b = 0; b < e->nb; b++) {
+            Block* bl = &w->blk[b];
+            const float* o = s + 64 + 13 * b;
+            for (int a = 0; a < 3; a++) { bl->pos[a] = o[a]; bl->vel[a] = o[7 + a]; bl->omg[a] = o[10 + a]; }
+            for (int a = 0; a < 4; a++) bl->quat[a] = o[3 + a];
+        }
+    }
+    return PMG_OK;
+}
+int pmgo_set_goal(pmgo_env* e, const uint8_t* mask, const float* goals)
+{
+    int G = e->dims.goal_dim;
+    for (int i = 0; i < e->cfg.num_envs; i++)
+        if (!mask || mask[i])
+            for (int g = 0; g < G; g++) e->w[i].goal[g] = goals[(size_t)i * G + g];
+    return PMG_OK;
+}
