@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the batched Kuka env on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one batched env.step() over 4096 envs per GPU (BASELINE.json
+configs[1]: task='reach', 4096 vectorised envs, random policy, state obs),
+actions pre-generated and resident in HBM, episodes reset every
+max_episode_steps=50 steps inside the timed region, and -- for N > 1 -- one RCCL
+all-gather of the packed observation shard per step.  Rank 0 prints ONE JSON line.
+
+torch is used only for device buffers of the synthetic action table and for
+the torch.distributed rendezvous; the env itself is the C-ABI HIP library.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic bytes per env-step (state r+w, action, outputs)
+ALGO_BYTES = {'reach': 298, 'push': 486, 'pick_and_place': 490, 'block_stack': 1246}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(task, budget_s=12.0):
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a
+    bounded sample of the same workload: 64 envs per core, random actions, until
+    ~budget_s of wall time has passed (at least 3 batched steps)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import oracle_lib
+    cores = os.cpu_count() or 1
+    n = 64 * cores
+    ora = oracle_lib.OracleEnv(task, n, seed_base=0, seed_stride=1, threads=cores)
+    ora.reset()
+    rs = np.random.RandomState(12345)
+    A = ora.dims.action_dim
+    steps = 0
+    t0 = time.perf_counter()
+    while True:
+        ora.step(rs.uniform(-1, 1, (n, A)).astype(np.float32))
+        steps += 1
+        el = time.perf_counter() - t0
+        if steps >= 3 and el >= budget_s:
+            break
+    ora.close()
+    return {'value': n * steps / el, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d envs x %d steps of task=%s on %d OpenMP threads (oracle/pmg_oracle.c, float64); '
+                      'PyBullet itself is absent on this box' % (n, steps, task, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--task', default='reach')
+    ap.add_argument('--envs-per-gpu', type=int, default=4096)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pybullet_multigoal_gym_amd as pmg
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('gloo')  # rendezvous + barrier only; the data path is RCCL inside the library
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, 50
+    env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=local_rank, seed=0, seed_stride=1,
+                       env_index_offset=rank * N, max_episode_steps=T)
+    h = env.handle
+    A = env.dims.action_dim
+    gathered = None
+    if world > 1:
+        uid = [h.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        h.comm_init(rank, world, uid[0])
+        gathered = torch.empty((world * N, env.dims.packed_dim), dtype=torch.float32, device=dev)
+    # synthetic random policy: a table of K+W batches of U(-1,1) actions, resident in HBM
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(12345 + rank)
+    actions = torch.rand((K + W, N, A), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+    torch.cuda.synchronize()
+
+    def run(first, count):
+        for t in range(first, first + count):
+            if t % T == 0:
+                h.reset_device(None)
+            h.step_device(actions[t].data_ptr())
+            if gathered is not None:
+                h.allgather_packed(gathered.data_ptr())
+
+    def fence():
+        h.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    run(0, W)
+    fence()
+    h.timing_reset()
+    t0 = time.perf_counter()
+    run(W, K)
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt[0])
+    kernel_ms, launches = h.timing_read()
+
+    if rank == 0:
+        value = world * N * K / el
+        algo = ALGO_BYTES[args.task] * N
+        achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        out = {
+            'metric': 'env-steps/sec at N_envs=4096/GPU, KukaReach' if args.task == 'reach' and N == 4096
+                      else 'env-steps/sec at N_envs=%d/GPU, %s' % (N, args.task),
+            'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': el / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': "task='%s', %d vectorised envs/GPU, random policy U(-1,1), state obs, binary reward, "
+                                   'reset every %d steps, 100 substeps/env-step' % (args.task, N, T),
+                       'global_envs': world * N, 'parallelism': 'env-shard x%d, RCCL all-gather of packed obs' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'pmg_k_step', 'kernel_ms': kernel_ms, 'launches': launches,
+                         'algorithmic_bytes_per_env_step': ALGO_BYTES[args.task],
+                         'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by '
+                                 'construction (SURVEY.md 8d); the binding resource is VALU issue / dependency latency'},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.task)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

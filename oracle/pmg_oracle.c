@@ -1375,13 +1375,15 @@ static void set_block(Block* b, real x, real y, real z)
     v3set(b->omg, 0, 0, 0);
 }
 
+static double norm2d(double x, double y) { return sqrt(x * x + y * y); } /* np.linalg.norm of a 2-vector */
+
 /* single-step task reset: kuka_single_step_base_env.py:76-148 */
 static void task_reset_single(const pmgo_env* e, World* w)
 {
     double center[3] = {e->tip_init[0], e->tip_init[1], e->tip_init[2]};
     if (e->has_obj) {
         double oxy[2] = {e->tip_init[0], e->tip_init[1]};
-        while (hypot(oxy[0] - e->tip_init[0], oxy[1] - e->tip_init[1]) < 0.1) {      /* :108-111 */
+        while (norm2d(oxy[0] - e->tip_init[0], oxy[1] - e->tip_init[1]) < 0.1) {      /* :108-111 */
             oxy[0] = mt_uniform(&w->rng, e->obj_lo[0], e->obj_hi[0]);
             oxy[1] = mt_uniform(&w->rng, e->obj_lo[1], e->obj_hi[1]);
         }
@@ -1420,8 +1422,8 @@ static void task_reset_stack(const pmgo_env* e, World* w)
             double y = mt_uniform(&w->rng, e->obj_lo[1], e->obj_hi[1]);
             int ok = 1;
             for (int c = 0; c < b; c++)
-                if (!(hypot(x - bp[c][0], y - bp[c][1]) > 0.06)) ok = 0;
-            if (!(hypot(x - e->tip_init[0], y - e->tip_init[1]) > 0.06)) ok = 0;
+                if (!(norm2d(x - bp[c][0], y - bp[c][1]) > 0.06)) ok = 0;
+            if (!(norm2d(x - e->tip_init[0], y - e->tip_init[1]) > 0.06)) ok = 0;
             if (ok) { bp[b][0] = x; bp[b][1] = y; break; }
         }
     }
@@ -1437,7 +1439,7 @@ static void task_reset_stack(const pmgo_env* e, World* w)
         double y = mt_uniform(&w->rng, e->tgt_lo[1], e->tgt_hi[1]);
         int ok = 1;
         for (int c = 0; c < e->nb; c++)
-            if (!(hypot(x - bp[c][0], y - bp[c][1]) > 0.08)) ok = 0;
+            if (!(norm2d(x - bp[c][0], y - bp[c][1]) > 0.08)) ok = 0;
         if (ok) { v3set(w->base_target, (real)x, (real)y, (real)0.175); break; }
     }
     stack_goal_from_order(e, w);

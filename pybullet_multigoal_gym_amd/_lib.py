@@ -1,0 +1,215 @@
+"""ctypes binding of the C ABI in include/pmg.h (libpmg_hip.so, built by hipcc for gfx950).
+
+There is no Python/NumPy fallback: if the shared library is missing this
+module raises at load time with the build command.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, 'csrc', 'libpmg_hip.so')
+
+TASK_IDS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4}
+PMG_BUF_PACKED = 7
+PMG_BUF_STATE = 8
+
+
+class PmgConfig(C.Structure):
+    _fields_ = [('struct_size', C.c_int32), ('task', C.c_int32), ('num_envs', C.c_int32), ('num_block', C.c_int32),
+                ('binary_reward', C.c_int32), ('joint_control', C.c_int32), ('max_episode_steps', C.c_int32),
+                ('device', C.c_int32), ('distance_threshold', C.c_float), ('random_order', C.c_int32),
+                ('seed_base', C.c_uint64), ('seed_stride', C.c_uint64), ('env_index_offset', C.c_int32),
+                ('reserved', C.c_int32 * 7)]
+
+
+class PmgDims(C.Structure):
+    _fields_ = [('num_envs', C.c_int32), ('action_dim', C.c_int32), ('observation_dim', C.c_int32),
+                ('policy_state_dim', C.c_int32), ('goal_dim', C.c_int32), ('state_dim', C.c_int32),
+                ('packed_dim', C.c_int32), ('reserved', C.c_int32)]
+
+
+class PmgError(RuntimeError):
+    pass
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class PmgLibrary:
+    """A loaded libpmg_hip.so with typed entry points."""
+
+    SYMBOLS = ['pmg_create', 'pmg_destroy', 'pmg_get_dims', 'pmg_last_error', 'pmg_seed', 'pmg_reset', 'pmg_step',
+               'pmg_reset_device', 'pmg_step_device', 'pmg_device_ptr', 'pmg_stream', 'pmg_sync', 'pmg_read_outputs',
+               'pmg_compute_reward', 'pmg_compute_reward_device', 'pmg_get_state', 'pmg_set_state', 'pmg_set_goal',
+               'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_read']
+
+    def __init__(self, path=None):
+        self.path = path or DEFAULT_LIBRARY
+        if not os.path.exists(self.path):
+            raise PmgError('%s not found: the HIP extension is not built (run `python -c "import __graft_entry__ as g; '
+                           'g.build()"` or `make -C pybullet_multigoal_gym_amd/csrc`). There is no CPU fallback.' % self.path)
+        self.lib = C.CDLL(self.path)
+        L = self.lib
+        for s in self.SYMBOLS:
+            getattr(L, s)  # raises AttributeError if the ABI is incomplete
+        L.pmg_last_error.restype = C.c_char_p
+        L.pmg_last_error.argtypes = [C.c_void_p]
+        L.pmg_destroy.restype = None
+        L.pmg_destroy.argtypes = [C.c_void_p]
+        for name in self.SYMBOLS:
+            if name not in ('pmg_last_error', 'pmg_destroy'):
+                getattr(L, name).restype = C.c_int
+
+    def error(self, handle=None):
+        msg = self.lib.pmg_last_error(handle)
+        return msg.decode() if msg else ''
+
+
+_default = None
+
+
+def default_library():
+    global _default
+    if _default is None:
+        _default = PmgLibrary()
+    return _default
+
+
+class PmgHandle:
+    """One pmg_env handle (N envs on one GPU)."""
+
+    def __init__(self, library, **cfg_kw):
+        self.L = library
+        cfg = PmgConfig()
+        cfg.struct_size = C.sizeof(PmgConfig)
+        for k, v in cfg_kw.items():
+            setattr(cfg, k, v)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = library.lib.pmg_create(C.byref(cfg), C.byref(self.h))
+        if rc != 0:
+            self.h = None
+            raise PmgError('pmg_create failed (%d): %s' % (rc, library.error(None)))
+        self.dims = PmgDims()
+        self._check(library.lib.pmg_get_dims(self.h, C.byref(self.dims)))
+        self.N = self.dims.num_envs
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PmgError('pmg call failed (%d): %s' % (rc, self.L.error(self.h)))
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.lib.pmg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host-buffer calls -------------------------------------------------
+    def _obs_bufs(self):
+        d, N = self.dims, self.N
+        return (np.empty((N, d.observation_dim), np.float32), np.empty((N, d.policy_state_dim), np.float32),
+                np.empty((N, d.goal_dim), np.float32), np.empty((N, d.goal_dim), np.float32))
+
+    def seed(self, base, stride):
+        self._check(self.L.lib.pmg_seed(self.h, C.c_uint64(base), C.c_uint64(stride)))
+
+    def reset(self, mask=None):
+        o, p, a, g = self._obs_bufs()
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.N)
+        self._check(self.L.lib.pmg_reset(self.h, _p(m), _p(o), _p(p), _p(a), _p(g)))
+        return o, p, a, g
+
+    def step(self, actions):
+        o, p, a, g = self._obs_bufs()
+        r = np.empty(self.N, np.float32)
+        ok = np.empty(self.N, np.uint8)
+        dn = np.empty(self.N, np.uint8)
+        self._check(self.L.lib.pmg_step(self.h, _p(actions), _p(o), _p(p), _p(a), _p(g), _p(r), _p(ok), _p(dn)))
+        return o, p, a, g, r, ok.astype(np.bool_), dn.astype(np.bool_)
+
+    def read_outputs(self):
+        o, p, a, g = self._obs_bufs()
+        r = np.empty(self.N, np.float32)
+        ok = np.empty(self.N, np.uint8)
+        dn = np.empty(self.N, np.uint8)
+        self._check(self.L.lib.pmg_read_outputs(self.h, _p(o), _p(p), _p(a), _p(g), _p(r), _p(ok), _p(dn)))
+        return o, p, a, g, r, ok.astype(np.bool_), dn.astype(np.bool_)
+
+    def compute_reward(self, ag, dg):
+        G = self.dims.goal_dim
+        ag = np.ascontiguousarray(ag, np.float32)
+        dg = np.ascontiguousarray(dg, np.float32)
+        if ag.shape != dg.shape or ag.shape[-1] != G:
+            raise ValueError('achieved_goal %s / desired_goal %s must share a shape ending in %d' % (ag.shape, dg.shape, G))
+        B = ag.size // G
+        r = np.empty(B, np.float32)
+        ok = np.empty(B, np.uint8)
+        self._check(self.L.lib.pmg_compute_reward(self.h, _p(ag), _p(dg), C.c_int64(B), _p(r), _p(ok)))
+        return r.reshape(ag.shape[:-1]), ok.astype(np.bool_).reshape(ag.shape[:-1])
+
+    def get_state(self):
+        s = np.empty((self.N, self.dims.state_dim), np.float32)
+        self._check(self.L.lib.pmg_get_state(self.h, _p(s)))
+        return s
+
+    def set_state(self, s):
+        s = np.ascontiguousarray(s, np.float32)
+        if s.shape != (self.N, self.dims.state_dim):
+            raise ValueError('state must have shape %s' % ((self.N, self.dims.state_dim),))
+        self._check(self.L.lib.pmg_set_state(self.h, _p(s)))
+
+    def set_goal(self, goals, mask=None):
+        goals = np.ascontiguousarray(goals, np.float32).reshape(self.N, self.dims.goal_dim)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.N)
+        self._check(self.L.lib.pmg_set_goal(self.h, _p(m), _p(goals)))
+
+    # -- device-resident calls --------------------------------------------
+    def step_device(self, d_actions_ptr):
+        self._check(self.L.lib.pmg_step_device(self.h, C.c_void_p(d_actions_ptr)))
+
+    def reset_device(self, d_mask_ptr=None):
+        self._check(self.L.lib.pmg_reset_device(self.h, C.c_void_p(d_mask_ptr) if d_mask_ptr else None))
+
+    def device_ptr(self, which=PMG_BUF_PACKED):
+        p = C.c_void_p()
+        self._check(self.L.lib.pmg_device_ptr(self.h, C.c_int(which), C.byref(p)))
+        return p.value
+
+    def stream(self):
+        p = C.c_void_p()
+        self._check(self.L.lib.pmg_stream(self.h, C.byref(p)))
+        return p.value
+
+    def sync(self):
+        self._check(self.L.lib.pmg_sync(self.h))
+
+    def timing_reset(self):
+        self._check(self.L.lib.pmg_timing_reset(self.h))
+
+    def timing_read(self):
+        ms = C.c_double()
+        n = C.c_int64()
+        self._check(self.L.lib.pmg_timing_read(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        rc = self.L.lib.pmg_comm_unique_id(buf)
+        if rc != 0:
+            raise PmgError('pmg_comm_unique_id failed (%d)' % rc)
+        return bytes(buf)
+
+    def comm_init(self, rank, nranks, uid):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self.L.lib.pmg_comm_init(self.h, C.c_int(rank), C.c_int(nranks), buf))
+
+    def allgather_packed(self, d_out_ptr):
+        self._check(self.L.lib.pmg_allgather_packed(self.h, C.c_void_p(d_out_ptr)))

@@ -1,0 +1,567 @@
+/*
+ * pmg_api.cpp -- host side of the C ABI declared in include/pmg.h.
+ *
+ * Owns the device arrays of N environments on one MI355X, seeds them like
+ * gym.utils.seeding.np_random (sha512 -> MT19937 init_by_array), launches
+ * the step / reset kernels on its own HIP stream, times the step kernel with
+ * HIP events, and exchanges the packed observation shard with RCCL.
+ * There is no CPU fallback: without a HIP device pmg_create fails.
+ */
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/pmg.h"
+#include "../../include/pmg_sha512_const.h"
+#include "pmg_launch.h"
+
+namespace {
+
+char g_create_err[512] = "";
+
+constexpr int EVENT_POOL = 2048;
+
+struct Seeder { /* gym 0.17.3 seeding.np_random + numpy RandomState.seed(int list) */
+    static inline uint64_t rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+    static void sha512(const unsigned char* msg, size_t len, unsigned char out[64])
+    {
+        static const uint64_t K[80] = PMG_SHA512_K;
+        uint64_t h[8] = PMG_SHA512_H0;
+        size_t total = ((len + 17 + 127) / 128) * 128;
+        std::vector<unsigned char> buf(total, 0);
+        memcpy(buf.data(), msg, len);
+        buf[len] = 0x80;
+        uint64_t bits = (uint64_t)len * 8;
+        for (int i = 0; i < 8; i++) buf[total - 1 - i] = (unsigned char)(bits >> (8 * i));
+        for (size_t off = 0; off < total; off += 128) {
+            uint64_t w[80];
+            for (int i = 0; i < 16; i++) {
+                uint64_t v = 0;
+                for (int b = 0; b < 8; b++) v = (v << 8) | buf[off + 8 * i + b];
+                w[i] = v;
+            }
+            for (int i = 16; i < 80; i++) {
+                uint64_t s0 = rotr(w[i - 15], 1) ^ rotr(w[i - 15], 8) ^ (w[i - 15] >> 7);
+                uint64_t s1 = rotr(w[i - 2], 19) ^ rotr(w[i - 2], 61) ^ (w[i - 2] >> 6);
+                w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+            }
+            uint64_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+            for (int i = 0; i < 80; i++) {
+                uint64_t t1 = hh + (rotr(e, 14) ^ rotr(e, 18) ^ rotr(e, 41)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+                uint64_t t2 = (rotr(a, 28) ^ rotr(a, 34) ^ rotr(a, 39)) + ((a & b) ^ (a & c) ^ (b & c));
+                hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+            }
+            h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+        }
+        for (int i = 0; i < 8; i++)
+            for (int b = 0; b < 8; b++) out[8 * i + b] = (unsigned char)(h[i] >> (56 - 8 * b));
+    }
+    /* fills mt[0..623] and mt[624] = 624 (index) */
+    static void seed(uint32_t* mt, uint64_t seed)
+    {
+        char txt[32];
+        int n = snprintf(txt, sizeof(txt), "%llu", (unsigned long long)seed);
+        unsigned char dig[64];
+        sha512((const unsigned char*)txt, (size_t)n, dig);
+        uint32_t key[2];
+        for (int w = 0; w < 2; w++)
+            key[w] = (uint32_t)dig[4 * w] | ((uint32_t)dig[4 * w + 1] << 8) | ((uint32_t)dig[4 * w + 2] << 16) | ((uint32_t)dig[4 * w + 3] << 24);
+        int klen = key[1] ? 2 : 1;
+        mt[0] = 19650218u;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        int i = 1, j = 0;
+        for (int k = 624; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            i++; j++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (j >= klen) j = 0;
+        }
+        for (int k = 623; k; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            i++;
+            if (i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+        mt[624] = 624u;
+    }
+};
+
+}  // namespace
+
+struct pmg_env {
+    pmg_config cfg;
+    pmg_dims dims;
+    pmg::EnvParams P;
+    int nb;
+    hipStream_t stream = nullptr;
+    float* d_actions = nullptr;       /* staging for host-buffer pmg_step */
+    unsigned char* d_mask = nullptr;
+    float* h_packed = nullptr;        /* pinned */
+    float* h_actions = nullptr;       /* pinned */
+    float* d_rw_ag = nullptr; float* d_rw_dg = nullptr; float* d_rw_r = nullptr; unsigned char* d_rw_ok = nullptr;
+    long long rw_cap = 0;
+    hipEvent_t ev_a[EVENT_POOL], ev_b[EVENT_POOL];
+    int ev_n = 0;
+    double ev_ms = 0.0;
+    long long ev_launches = 0;
+    bool ever_reset = false;
+    ncclComm_t comm = nullptr;
+    int nranks = 1, rank = 0;
+    char err[512] = "";
+};
+
+namespace {
+
+int fail(pmg_env* e, int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e ? e->err : g_create_err, 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(e, call)                                                                             \
+    do {                                                                                             \
+        hipError_t rc_ = (call);                                                                     \
+        if (rc_ != hipSuccess) return fail(e, PMG_E_DEVICE, "%s -> %s", #call, hipGetErrorString(rc_)); \
+    } while (0)
+
+int fill_dims(const pmg_config* c, pmg_dims* d, int* nb_out)
+{
+    memset(d, 0, sizeof(*d));
+    int jo = c->joint_control ? 7 : 0;
+    d->num_envs = c->num_envs;
+    switch (c->task) {
+    case PMG_TASK_REACH: d->action_dim = jo ? 7 : 3; d->observation_dim = 3 + jo; d->policy_state_dim = 3 + jo; d->goal_dim = 3; break;
+    case PMG_TASK_PUSH: d->action_dim = jo ? 7 : 3; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
+    case PMG_TASK_PICK_AND_PLACE: d->action_dim = jo ? 8 : 4; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
+    case PMG_TASK_BLOCK_STACK:
+        if (c->num_block < 1 || c->num_block > 5) return -1;
+        d->action_dim = jo ? 8 : 4; d->observation_dim = 8 + 16 * c->num_block + jo;
+        d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; break;
+    default: return -1; /* slide (cylinder puck) is not built yet */
+    }
+    int nb = c->task == PMG_TASK_REACH ? 0 : (c->task == PMG_TASK_BLOCK_STACK ? c->num_block : 1);
+    *nb_out = nb;
+    d->state_dim = 64 + 13 * nb;
+    d->packed_dim = d->observation_dim + d->policy_state_dim + 2 * d->goal_dim + 3;
+    return 0;
+}
+
+/* workspace constants: kuka.py:35-51, kuka_single_step_base_env.py:48-56 */
+void fill_params(pmg_env* e)
+{
+    pmg::EnvParams& P = e->P;
+    const pmg_config& c = e->cfg;
+    int t = c.task;
+    P.n_envs = c.num_envs; P.task = t; P.nb = e->nb;
+    P.grasping = (t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
+    P.has_obj = (t != PMG_TASK_REACH);
+    P.in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
+    P.joint_control = c.joint_control; P.binary_reward = c.binary_reward; P.max_steps = c.max_episode_steps;
+    P.random_order = c.random_order;
+    P.adim = e->dims.action_dim; P.odim = e->dims.observation_dim; P.pdim = e->dims.policy_state_dim;
+    P.gdim = e->dims.goal_dim; P.packed = e->dims.packed_dim;
+    P.thr = c.distance_threshold;
+    bool on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE);
+    double range = 0.15;
+    P.tip_init[0] = -0.52; P.tip_init[1] = 0.0; P.tip_init[2] = 0.25;
+    if (on_table) P.tip_init[2] = 0.175 + 0.001;
+    const double hi[3] = {-0.37, 0.20, 0.55}, lo[3] = {-0.67, -0.20, 0.175};
+    for (int a = 0; a < 3; a++) {
+        P.ee_hi[a] = (float)hi[a]; P.ee_lo[a] = (float)lo[a];
+        P.obj_lo[a] = P.tip_init[a] - range; P.obj_hi[a] = P.tip_init[a] + range;
+        P.tgt_lo[a] = P.tip_init[a] - range; P.tgt_hi[a] = P.tip_init[a] + range;
+    }
+    P.obj_lo[0] += 0.03; P.obj_hi[0] -= 0.03;
+    P.tgt_lo[0] += 0.03; P.tgt_hi[0] -= 0.03;
+    P.tgt_lo[2] = lo[2];
+    P.obj_z = 0.175;
+    const float th[3] = PMG_TABLE_HALF;
+    P.table_c[0] = -0.52f; P.table_c[1] = 0.f; P.table_c[2] = 0.08f;
+    for (int a = 0; a < 3; a++) P.table_h[a] = th[a];
+    P.table_mu = (float)PMG_TABLE_FRICTION;
+}
+
+int upload_seeds(pmg_env* e)
+{
+    int N = e->cfg.num_envs;
+    std::vector<uint32_t> mt((size_t)N * 625);
+    for (int i = 0; i < N; i++)
+        Seeder::seed(mt.data() + (size_t)i * 625, e->cfg.seed_base + e->cfg.seed_stride * (uint64_t)(i + e->cfg.env_index_offset));
+    HIP_TRY(e, hipMemcpyAsync(e->P.rng, mt.data(), mt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return PMG_OK;
+}
+
+void unpack(const pmg_env* e, const float* packed, float* obs, float* pol, float* ag, float* dg, float* reward,
+            uint8_t* ga, uint8_t* done)
+{
+    const pmg_dims& d = e->dims;
+    int N = d.num_envs, S = d.packed_dim;
+    for (int i = 0; i < N; i++) {
+        const float* r = packed + (size_t)i * S;
+        if (obs) memcpy(obs + (size_t)i * d.observation_dim, r, sizeof(float) * d.observation_dim);
+        r += d.observation_dim;
+        if (pol) memcpy(pol + (size_t)i * d.policy_state_dim, r, sizeof(float) * d.policy_state_dim);
+        r += d.policy_state_dim;
+        if (ag) memcpy(ag + (size_t)i * d.goal_dim, r, sizeof(float) * d.goal_dim);
+        r += d.goal_dim;
+        if (dg) memcpy(dg + (size_t)i * d.goal_dim, r, sizeof(float) * d.goal_dim);
+        r += d.goal_dim;
+        if (reward) reward[i] = r[0];
+        if (ga) ga[i] = r[1] != 0.f;
+        if (done) done[i] = r[2] != 0.f;
+    }
+}
+
+void drain_events(pmg_env* e)
+{
+    for (int i = 0; i < e->ev_n; i++) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(e->ev_b[i]);
+        if (hipEventElapsedTime(&ms, e->ev_a[i], e->ev_b[i]) == hipSuccess) { e->ev_ms += ms; e->ev_launches++; }
+    }
+    e->ev_n = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pmg_last_error(const pmg_env* e) { return e ? e->err : g_create_err; }
+
+int pmg_create(const pmg_config* cfg, pmg_env** out)
+{
+    if (!cfg || !out) return fail(nullptr, PMG_E_INVALID, "pmg_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(pmg_config)) return fail(nullptr, PMG_E_INVALID, "pmg_create: struct_size %d != %zu", cfg->struct_size, sizeof(pmg_config));
+    if (cfg->num_envs < 1) return fail(nullptr, PMG_E_INVALID, "pmg_create: num_envs must be >= 1");
+    if (cfg->max_episode_steps < 1) return fail(nullptr, PMG_E_INVALID, "pmg_create: max_episode_steps must be >= 1");
+    pmg_dims dims;
+    int nb = 0;
+    if (fill_dims(cfg, &dims, &nb) != 0)
+        return fail(nullptr, PMG_E_INVALID, "pmg_create: unsupported task %d / num_block %d", cfg->task, cfg->num_block);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, PMG_E_DEVICE, "pmg_create: no HIP device visible (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, PMG_E_INVALID, "pmg_create: device %d out of range (%d visible)", cfg->device, ndev);
+    pmg_env* e = new pmg_env();
+    e->cfg = *cfg;
+    e->dims = dims;
+    e->nb = nb;
+    auto bail = [&](int code) { snprintf(g_create_err, sizeof(g_create_err), "%s", e->err); pmg_destroy(e); return code; };
+#define CREATE_TRY(call)                                                                         \
+    do {                                                                                         \
+        hipError_t rc_ = (call);                                                                 \
+        if (rc_ != hipSuccess) { fail(e, PMG_E_DEVICE, "%s -> %s", #call, hipGetErrorString(rc_)); return bail(PMG_E_DEVICE); } \
+    } while (0)
+    CREATE_TRY(hipSetDevice(cfg->device));
+    CREATE_TRY(hipStreamCreate(&e->stream));
+    size_t N = (size_t)cfg->num_envs;
+    fill_params(e);
+    CREATE_TRY(hipMalloc((void**)&e->P.hot, N * pmg::HOT_DIM * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->P.cold, N * pmg::COLD_DIM * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->P.goal, N * pmg::GOAL_DIM * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->P.blocks, N * pmg::BLOCK_DIM * (nb ? nb : 1) * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->P.rng, N * 625 * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->d_mask, N));
+    CREATE_TRY(hipHostMalloc((void**)&e->h_packed, N * dims.packed_dim * sizeof(float)));
+    CREATE_TRY(hipHostMalloc((void**)&e->h_actions, N * dims.action_dim * sizeof(float)));
+    for (int i = 0; i < EVENT_POOL; i++) { CREATE_TRY(hipEventCreate(&e->ev_a[i])); CREATE_TRY(hipEventCreate(&e->ev_b[i])); }
+    /* initial state: rest pose kuka.py:27, blocks parked below the floor */
+    {
+        static const float rest0[7] = {0.f, -0.5592432f, 0.f, 1.733180f, 0.f, -0.8501557f, 0.f};
+        std::vector<float> cold(N * pmg::COLD_DIM, 0.f), blk(N * pmg::BLOCK_DIM * (nb ? nb : 1), 0.f);
+        for (size_t i = 0; i < N; i++) {
+            memcpy(&cold[i * pmg::COLD_DIM], rest0, sizeof(rest0));
+            for (int b = 0; b < nb; b++) { float* o = &blk[(i * nb + b) * pmg::BLOCK_DIM]; o[2] = -3.f; o[6] = 1.f; }
+        }
+        CREATE_TRY(hipMemcpy(e->P.cold, cold.data(), cold.size() * sizeof(float), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(e->P.blocks, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemset(e->P.hot, 0, N * pmg::HOT_DIM * sizeof(float)));
+        CREATE_TRY(hipMemset(e->P.goal, 0, N * pmg::GOAL_DIM * sizeof(float)));
+        CREATE_TRY(hipMemset(e->P.out, 0, N * dims.packed_dim * sizeof(float)));
+    }
+    if (upload_seeds(e) != PMG_OK) return bail(PMG_E_DEVICE);
+    *out = e;
+    return PMG_OK;
+}
+
+void pmg_destroy(pmg_env* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->comm) ncclCommDestroy(e->comm);
+    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out);
+    (void)hipFree(e->d_actions); (void)hipFree(e->d_mask);
+    (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
+    if (e->h_packed) (void)hipHostFree(e->h_packed);
+    if (e->h_actions) (void)hipHostFree(e->h_actions);
+    for (int i = 0; i < EVENT_POOL; i++) { if (e->ev_a[i]) (void)hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) (void)hipEventDestroy(e->ev_b[i]); }
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int pmg_get_dims(const pmg_env* e, pmg_dims* out)
+{
+    if (!e || !out) return PMG_E_INVALID;
+    *out = e->dims;
+    return PMG_OK;
+}
+
+int pmg_seed(pmg_env* e, uint64_t base, uint64_t stride)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    e->cfg.seed_base = base;
+    e->cfg.seed_stride = stride;
+    return upload_seeds(e);
+}
+
+int pmg_reset_device(pmg_env* e, const uint8_t* d_mask)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, pmg_launch_reset(e->P, d_mask, e->stream));
+    if (!d_mask) e->ever_reset = true;
+    return PMG_OK;
+}
+
+int pmg_step_device(pmg_env* e, const float* d_actions)
+{
+    if (!e || !d_actions) return PMG_E_INVALID;
+    if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_step: reset() must be called (for all envs) before the first step()");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (e->ev_n == EVENT_POOL) drain_events(e);
+    int i = e->ev_n++;
+    HIP_TRY(e, hipEventRecord(e->ev_a[i], e->stream));
+    HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream));
+    HIP_TRY(e, hipEventRecord(e->ev_b[i], e->stream));
+    return PMG_OK;
+}
+
+int pmg_read_outputs(pmg_env* e, float* obs, float* pol, float* ag, float* dg, float* reward, uint8_t* ga, uint8_t* done)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    size_t bytes = (size_t)e->dims.num_envs * e->dims.packed_dim * sizeof(float);
+    HIP_TRY(e, hipMemcpyAsync(e->h_packed, e->P.out, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    unpack(e, e->h_packed, obs, pol, ag, dg, reward, ga, done);
+    return PMG_OK;
+}
+
+int pmg_reset(pmg_env* e, const uint8_t* mask, float* obs, float* pol, float* ag, float* dg)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const uint8_t* dm = nullptr;
+    if (mask) {
+        if (!e->ever_reset) {
+            for (int i = 0; i < e->dims.num_envs; i++)
+                if (!mask[i]) return fail(e, PMG_E_STATE, "pmg_reset: the first reset must cover every env");
+        }
+        HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, (size_t)e->dims.num_envs, hipMemcpyHostToDevice, e->stream));
+        dm = e->d_mask;
+    }
+    int rc = pmg_reset_device(e, dm);
+    if (rc != PMG_OK) return rc;
+    e->ever_reset = true;
+    return pmg_read_outputs(e, obs, pol, ag, dg, nullptr, nullptr, nullptr);
+}
+
+int pmg_step(pmg_env* e, const float* actions, float* obs, float* pol, float* ag, float* dg, float* reward, uint8_t* ga, uint8_t* done)
+{
+    if (!e || !actions) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    size_t n = (size_t)e->dims.num_envs * e->dims.action_dim;
+    for (size_t i = 0; i < n; i++) {
+        /* kuka.py:168 assert action_space.contains(a): Box(-1, 1) */
+        if (!(actions[i] >= -1.f && actions[i] <= 1.f)) return fail(e, PMG_E_INVALID, "pmg_step: action[%zu] = %g is outside [-1, 1]", i, (double)actions[i]);
+        e->h_actions[i] = actions[i];
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->d_actions, e->h_actions, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int rc = pmg_step_device(e, e->d_actions);
+    if (rc != PMG_OK) return rc;
+    return pmg_read_outputs(e, obs, pol, ag, dg, reward, ga, done);
+}
+
+int pmg_device_ptr(pmg_env* e, int which, void** d_ptr)
+{
+    if (!e || !d_ptr) return PMG_E_INVALID;
+    switch (which) {
+    case PMG_BUF_PACKED: *d_ptr = e->P.out; return PMG_OK;
+    case PMG_BUF_STATE: *d_ptr = e->P.hot; return PMG_OK;
+    default: return fail(e, PMG_E_INVALID, "pmg_device_ptr: buffer %d is not a device buffer (use PMG_BUF_PACKED + pmg_dims offsets)", which);
+    }
+}
+int pmg_stream(pmg_env* e, void** s)
+{
+    if (!e || !s) return PMG_E_INVALID;
+    *s = (void*)e->stream;
+    return PMG_OK;
+}
+int pmg_sync(pmg_env* e)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return PMG_OK;
+}
+
+int pmg_compute_reward_device(pmg_env* e, const float* d_ag, const float* d_dg, int64_t batch, float* d_r, uint8_t* d_ok)
+{
+    if (!e || !d_ag || !d_dg || batch < 0) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, pmg_launch_reward(d_ag, d_dg, batch, e->dims.goal_dim, e->cfg.distance_threshold, e->cfg.binary_reward, d_r, d_ok, e->stream));
+    return PMG_OK;
+}
+
+int pmg_compute_reward(pmg_env* e, const float* ag, const float* dg, int64_t batch, float* r, uint8_t* ok)
+{
+    if (!e || !ag || !dg || batch < 0) return PMG_E_INVALID;
+    if (batch == 0) return PMG_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    int G = e->dims.goal_dim;
+    if (batch > e->rw_cap) {
+        (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
+        e->d_rw_ag = e->d_rw_dg = e->d_rw_r = nullptr; e->d_rw_ok = nullptr; e->rw_cap = 0;
+        HIP_TRY(e, hipMalloc((void**)&e->d_rw_ag, (size_t)batch * G * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->d_rw_dg, (size_t)batch * G * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->d_rw_r, (size_t)batch * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&e->d_rw_ok, (size_t)batch));
+        e->rw_cap = batch;
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->d_rw_ag, ag, (size_t)batch * G * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_rw_dg, dg, (size_t)batch * G * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    int rc = pmg_compute_reward_device(e, e->d_rw_ag, e->d_rw_dg, batch, e->d_rw_r, e->d_rw_ok);
+    if (rc != PMG_OK) return rc;
+    if (r) HIP_TRY(e, hipMemcpyAsync(r, e->d_rw_r, (size_t)batch * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (ok) HIP_TRY(e, hipMemcpyAsync(ok, e->d_rw_ok, (size_t)batch, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return PMG_OK;
+}
+
+/* state row = hot(32) | cold(16) | goal(16) | blocks(13 nb)    */
+int pmg_get_state(pmg_env* e, float* state)
+{
+    if (!e || !state) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    size_t N = (size_t)e->dims.num_envs;
+    int S = e->dims.state_dim, nbd = pmg::BLOCK_DIM * e->nb;
+    std::vector<float> hot(N * pmg::HOT_DIM), cold(N * pmg::COLD_DIM), goal(N * pmg::GOAL_DIM), blk(N * (nbd ? nbd : 1));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(hot.data(), e->P.hot, hot.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(cold.data(), e->P.cold, cold.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(goal.data(), e->P.goal, goal.size() * sizeof(float), hipMemcpyDeviceToHost));
+    if (nbd) HIP_TRY(e, hipMemcpy(blk.data(), e->P.blocks, N * nbd * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        float* s = state + i * S;
+        memcpy(s, &hot[i * pmg::HOT_DIM], sizeof(float) * pmg::HOT_DIM);
+        memcpy(s + 32, &cold[i * pmg::COLD_DIM], sizeof(float) * pmg::COLD_DIM);
+        memcpy(s + 48, &goal[i * pmg::GOAL_DIM], sizeof(float) * pmg::GOAL_DIM);
+        if (nbd) memcpy(s + 64, &blk[i * nbd], sizeof(float) * nbd);
+    }
+    return PMG_OK;
+}
+
+int pmg_set_state(pmg_env* e, const float* state)
+{
+    if (!e || !state) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    size_t N = (size_t)e->dims.num_envs;
+    int S = e->dims.state_dim, nbd = pmg::BLOCK_DIM * e->nb;
+    std::vector<float> hot(N * pmg::HOT_DIM), cold(N * pmg::COLD_DIM), goal(N * pmg::GOAL_DIM), blk(N * (nbd ? nbd : 1));
+    for (size_t i = 0; i < N; i++) {
+        const float* s = state + i * S;
+        memcpy(&hot[i * pmg::HOT_DIM], s, sizeof(float) * pmg::HOT_DIM);
+        memcpy(&cold[i * pmg::COLD_DIM], s + 32, sizeof(float) * pmg::COLD_DIM);
+        memcpy(&goal[i * pmg::GOAL_DIM], s + 48, sizeof(float) * pmg::GOAL_DIM);
+        if (nbd) memcpy(&blk[i * nbd], s + 64, sizeof(float) * nbd);
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(e->P.hot, hot.data(), hot.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->P.cold, cold.data(), cold.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->P.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (nbd) HIP_TRY(e, hipMemcpy(e->P.blocks, blk.data(), N * nbd * sizeof(float), hipMemcpyHostToDevice));
+    e->ever_reset = true;
+    return PMG_OK;
+}
+
+int pmg_set_goal(pmg_env* e, const uint8_t* mask, const float* goals)
+{
+    if (!e || !goals) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    size_t N = (size_t)e->dims.num_envs;
+    int G = e->dims.goal_dim;
+    std::vector<float> goal(N * pmg::GOAL_DIM);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(goal.data(), e->P.goal, goal.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++)
+        if (!mask || mask[i]) memcpy(&goal[i * pmg::GOAL_DIM], goals + i * G, sizeof(float) * G);
+    HIP_TRY(e, hipMemcpy(e->P.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PMG_OK;
+}
+
+int pmg_comm_unique_id(uint8_t id[128])
+{
+    ncclUniqueId u;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    if (ncclGetUniqueId(&u) != ncclSuccess) return PMG_E_COMM;
+    memcpy(id, &u, 128);
+    return PMG_OK;
+}
+int pmg_comm_init(pmg_env* e, int rank, int nranks, const uint8_t id[128])
+{
+    if (!e || !id || nranks < 1 || rank < 0 || rank >= nranks) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclResult_t rc = ncclCommInitRank(&e->comm, nranks, u, rank);
+    if (rc != ncclSuccess) return fail(e, PMG_E_COMM, "ncclCommInitRank -> %s", ncclGetErrorString(rc));
+    e->rank = rank;
+    e->nranks = nranks;
+    return PMG_OK;
+}
+int pmg_allgather_packed(pmg_env* e, float* d_gathered)
+{
+    if (!e || !d_gathered) return PMG_E_INVALID;
+    if (!e->comm) return fail(e, PMG_E_STATE, "pmg_allgather_packed: pmg_comm_init was not called");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    size_t count = (size_t)e->dims.num_envs * e->dims.packed_dim;
+    ncclResult_t rc = ncclAllGather(e->P.out, d_gathered, count, ncclFloat, e->comm, e->stream);
+    if (rc != ncclSuccess) return fail(e, PMG_E_COMM, "ncclAllGather -> %s", ncclGetErrorString(rc));
+    return PMG_OK;
+}
+
+int pmg_timing_reset(pmg_env* e)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->ev_n = 0;
+    e->ev_ms = 0.0;
+    e->ev_launches = 0;
+    return PMG_OK;
+}
+int pmg_timing_read(pmg_env* e, double* avg_ms, int64_t* launches)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    drain_events(e);
+    if (avg_ms) *avg_ms = e->ev_launches ? e->ev_ms / (double)e->ev_launches : 0.0;
+    if (launches) *launches = e->ev_launches;
+    return PMG_OK;
+}
+
+}  /* extern "C" */

@@ -1,0 +1,630 @@
+/*
+ * pmg_device.h -- device code of the per-step hot path, one wavefront per env.
+ *
+ * Replaces, for N envs at once, what the reference does through PyBullet in
+ * Kuka.apply_action (P/robots/kuka.py:167-225): tip-target integration and
+ * clipping, calculateInverseKinematics, POSITION_CONTROL motors and
+ * 5 x stepSimulation (= 100 substeps of 2 ms with 5 solver iterations,
+ * P/envs/base_envs/base_env.py:203-220), followed by the state read-out of
+ * Kuka.calc_robot_state (kuka.py:227-256).
+ *
+ * Layout: lane l < 9 owns movable link / DoF l (iiwa_joint_1..7, finger1,
+ * finger2) and keeps its link frame, spatial axis, inertia, velocity and its
+ * row of M^-1 in registers.  Chain recursions are DPP prefix/suffix scans in
+ * the first 16-lane row, matrix work is lane = row with v_readlane
+ * broadcasts; no MFMA (nothing here is a dense contraction), no HBM traffic
+ * inside the 100-substep loop.
+ *
+ * Spatial algebra: world coordinates, Pluecker vectors referenced to the
+ * world origin, motion = [w; v_O], force = [n_O; f].  A rigid-body inertia is
+ * the 10-vector (m, H = m c, Ibar about the origin: xx xy xz yy yz zz), so the
+ * composite-body recursion is a plain suffix SUM along the chain.
+ * Dynamics = CRBA (mass matrix) + RNEA (bias) + in-register Gauss-Jordan
+ * M^-1, mathematically identical to the articulated-body algorithm the
+ * oracle restates from Bullet.
+ */
+#ifndef PMG_DEVICE_H
+#define PMG_DEVICE_H
+
+#include <pmg_wave.h> /* -I csrc (gfx950) or -I tests/emu (CPU emulator) */
+#include "../../include/pmg.h"
+#include "../../include/pmg_model.h"
+
+namespace pmg {
+
+constexpr int NJ = 9;
+constexpr float DT = 0.002f;            /* base_env.py:217-219 */
+constexpr int SUBSTEPS = 20;            /* base_env.py:219 */
+constexpr int SIM_STEPS = 5;            /* kuka.py:223-225 */
+constexpr int SOLVER_ITERS = 5;         /* base_env.py:37 */
+constexpr float PHYSICS_DT = 0.04f;     /* base_env.py:217 */
+constexpr float GRAVITY = 9.81f;        /* base_env.py:17 */
+constexpr float CONTACT_ERP = 0.9f;     /* base_env.py:216 */
+constexpr float JOINT_ERP = 0.2f;
+constexpr float LINEAR_SLOP = 1e-5f;
+constexpr float RESIDUAL_THRESHOLD = 1e-7f;
+constexpr float LINK_DAMPING = 0.04f;
+constexpr float LIMIT_MAX_IMPULSE = 100.f;
+constexpr float ARM_KP = 0.03f, ARM_KD = 1.0f, ARM_FORCE = 200.f, FINGER_FORCE = 50.f; /* kuka.py:287-301 */
+constexpr float FINGER_LIMIT = 0.035f;  /* kuka.py:71 */
+constexpr int IK_MAX_ITER = 40;         /* kuka.py:278 */
+constexpr float IK_THRESHOLD = 1e-5f;   /* kuka.py:279 */
+constexpr float IK_DAMPING = 0.5f;
+constexpr float IK_MAX_STEP = 0.78539816339744830962f;
+constexpr float SIMD_EPS = 1.1920929e-07f;
+constexpr float TIP_Z = 0.12f;          /* iiwa_gripper_tip_joint, urdf:311-315 */
+
+/* state rows in HBM (float32, DESIGN.md "state rows") */
+constexpr int HOT_DIM = 32;   /* q9 qd9 ee3 jt7 grip elapsed enabled resets */
+constexpr int COLD_DIM = 16;  /* rest7 - order5 base3 */
+constexpr int GOAL_DIM = 16;
+constexpr int BLOCK_DIM = 13; /* pos3 quat4 vel3 omg3 */
+
+__constant__ float C_JXYZ[NJ][3] = PMG_JXYZ;
+__constant__ float C_JROT[NJ][3][3] = PMG_JROT;
+__constant__ float C_JAXIS[NJ][3] = PMG_JAXIS;
+__constant__ int C_JTYPE[NJ] = PMG_JTYPE;
+__constant__ float C_JLO[NJ] = PMG_JLO;
+__constant__ float C_JHI[NJ] = PMG_JHI;
+__constant__ float C_JDAMP[NJ] = PMG_JDAMP;
+__constant__ float C_MASS[NJ] = PMG_MB_MASS;
+__constant__ float C_H[NJ][3] = PMG_MB_H;
+__constant__ float C_ILO[NJ][6] = PMG_MB_ILO;
+__constant__ float C_DSUM[NJ][3] = PMG_MB_DSUM;
+__constant__ float C_SUBM[NJ][2] = PMG_MB_SUBM_MASS;
+__constant__ float C_SUBC[NJ][2][3] = PMG_MB_SUBM_COM;
+/* motor/limit row order of the non-contact constraint list (PMG_ROW_ORDER) */
+__constant__ int C_ROWDOF[NJ] = {2, 3, 0, 1, 4, 7, 8, 5, 6};
+
+/* ---------------------------------------------------------------- */
+struct LaneConst { /* per-lane (= per movable link) model constants */
+    float rf[9], xyz[3], ax[3];
+    int prismatic;
+    float mass, h[3], ilo[6], dsum[3], sm[2], sc[2][3];
+    float jlo, jhi, jdamp;
+};
+
+__device__ __forceinline__ void load_lane_const(LaneConst& c)
+{
+    int l = wv::lane() < NJ ? wv::lane() : NJ - 1;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) c.rf[3 * a + b] = C_JROT[l][a][b];
+        c.xyz[a] = C_JXYZ[l][a];
+        c.ax[a] = C_JAXIS[l][a];
+        c.h[a] = C_H[l][a];
+        c.dsum[a] = C_DSUM[l][a];
+        c.sc[0][a] = C_SUBC[l][0][a];
+        c.sc[1][a] = C_SUBC[l][1][a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; a++) c.ilo[a] = C_ILO[l][a];
+    c.prismatic = C_JTYPE[l];
+    c.mass = C_MASS[l];
+    c.sm[0] = C_SUBM[l][0];
+    c.sm[1] = C_SUBM[l][1];
+    c.jlo = C_JLO[l];
+    c.jhi = C_JHI[l];
+    c.jdamp = C_JDAMP[l];
+}
+
+/* ---------------------------------------------------------------- */
+/* small vector helpers                                              */
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o)
+{
+    float x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ float dot6(const float* a, const float* b) { return dot3(a, b) + dot3(a + 3, b + 3); }
+/* o = R v, R row-major */
+__device__ __forceinline__ void mat3v(const float* R, const float* v, float* o)
+{
+    float x = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    float y = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    float z = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+__device__ __forceinline__ void mat3m(const float* A, const float* B, float* O)
+{
+    float t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) t[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) O[i] = t[i];
+}
+/* symmetric 3x3 (xx xy xz yy yz zz) times vector */
+__device__ __forceinline__ void sym3v(const float* I, const float* v, float* o)
+{
+    float x = I[0] * v[0] + I[1] * v[1] + I[2] * v[2];
+    float y = I[1] * v[0] + I[3] * v[1] + I[4] * v[2];
+    float z = I[2] * v[0] + I[4] * v[1] + I[5] * v[2];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+/* rigid inertia (m, H, Ibar) times motion vector -> force vector */
+__device__ __forceinline__ void inertia_mul(const float* I10, const float* mv, float* f)
+{
+    float t[3], u[3];
+    sym3v(I10 + 4, mv, t);
+    cross3(I10 + 1, mv + 3, u); /* H x v */
+    f[0] = t[0] + u[0]; f[1] = t[1] + u[1]; f[2] = t[2] + u[2];
+    cross3(mv, I10 + 1, u);     /* w x H */
+    f[3] = I10[0] * mv[3] + u[0]; f[4] = I10[0] * mv[4] + u[1]; f[5] = I10[0] * mv[5] + u[2];
+}
+/* motion x motion */
+__device__ __forceinline__ void crm(const float* v, const float* m, float* o)
+{
+    float a[3], b[3], c[3];
+    cross3(v, m, a);
+    cross3(v, m + 3, b);
+    cross3(v + 3, m, c);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2];
+    o[3] = b[0] + c[0]; o[4] = b[1] + c[1]; o[5] = b[2] + c[2];
+}
+/* motion x* force */
+__device__ __forceinline__ void crf(const float* v, const float* f, float* o)
+{
+    float a[3], b[3], c[3];
+    cross3(v, f, a);
+    cross3(v + 3, f + 3, b);
+    cross3(v, f + 3, c);
+    o[0] = a[0] + b[0]; o[1] = a[1] + b[1]; o[2] = a[2] + b[2];
+    o[3] = c[0]; o[4] = c[1]; o[5] = c[2];
+}
+
+/* inclusive sum over the joints on the path base -> this link (lanes 0..6 chain, 7/8 leaves of 6) */
+__device__ __forceinline__ float chain_prefix(float x)
+{
+    int l = wv::lane();
+    float y = l < 7 ? x : 0.f;
+    y += wv::row_shr<1>(y, 0.f);
+    y += wv::row_shr<2>(y, 0.f);
+    y += wv::row_shr<4>(y, 0.f);
+    float y6 = wv::bcast(y, 6);
+    return l < 7 ? y : y6 + x;
+}
+/* inclusive sum over the subtree of this link */
+__device__ __forceinline__ float chain_suffix(float x)
+{
+    int l = wv::lane();
+    float x7 = wv::bcast(x, 7), x8 = wv::bcast(x, 8);
+    float y = l < 6 ? x : (l == 6 ? (x + x7) + x8 : 0.f);
+    y += wv::row_shl<1>(y, 0.f);
+    y += wv::row_shl<2>(y, 0.f);
+    y += wv::row_shl<4>(y, 0.f);
+    return l < 7 ? y : x;
+}
+
+/* ---------------------------------------------------------------- */
+struct Kin {
+    float R[9], p[3]; /* world <- link frame */
+    float S[6];       /* joint motion subspace */
+};
+
+/* forward kinematics of the chain; lanes >= 9 end up holding link 7's frame (lane 6's) */
+__device__ __forceinline__ void fk(const LaneConst& c, float q, Kin& k)
+{
+    int l = wv::lane();
+    float Lo[12]; /* local rotation (9) + offset (3) in the parent frame */
+    float sq, cq;
+    sincosf(q, &sq, &cq);
+    if (c.prismatic) {
+        float d[3];
+        mat3v(c.rf, c.ax, d);
+#pragma unroll
+        for (int a = 0; a < 9; a++) Lo[a] = c.rf[a];
+#pragma unroll
+        for (int a = 0; a < 3; a++) Lo[9 + a] = c.xyz[a] + d[a] * q;
+    } else { /* revolute about local z: L = Rfix * Rz(q) */
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            Lo[3 * r] = c.rf[3 * r] * cq + c.rf[3 * r + 1] * sq;
+            Lo[3 * r + 1] = c.rf[3 * r + 1] * cq - c.rf[3 * r] * sq;
+            Lo[3 * r + 2] = c.rf[3 * r + 2];
+            Lo[9 + r] = c.xyz[r];
+        }
+    }
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        float Lj[12];
+        wv::bcastn<12>(Lo, j, Lj);
+        if (l >= j) {
+            float t[3];
+            mat3v(R, Lj + 9, t);
+            p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+            mat3m(R, Lj, R);
+        }
+    }
+    if (l == 7 || l == 8) {
+        float t[3];
+        mat3v(R, Lo + 9, t);
+        p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+        mat3m(R, Lo, R);
+    }
+#pragma unroll
+    for (int a = 0; a < 9; a++) k.R[a] = R[a];
+#pragma unroll
+    for (int a = 0; a < 3; a++) k.p[a] = p[a];
+    float aw[3];
+    mat3v(R, c.ax, aw);
+    if (c.prismatic) {
+        k.S[0] = k.S[1] = k.S[2] = 0.f;
+        k.S[3] = aw[0]; k.S[4] = aw[1]; k.S[5] = aw[2];
+    } else {
+        k.S[0] = aw[0]; k.S[1] = aw[1]; k.S[2] = aw[2];
+        cross3(p, aw, k.S + 3);
+    }
+    if (l >= NJ) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) k.S[a] = 0.f;
+    }
+}
+
+/* tip frame (uniform): tip position and the rotation of link 7 */
+__device__ __forceinline__ void tip_frame(const Kin& k, float* tip, float* Rt)
+{
+    float t[12];
+#pragma unroll
+    for (int a = 0; a < 3; a++) t[a] = k.p[a] + k.R[3 * a + 2] * TIP_Z;
+#pragma unroll
+    for (int a = 0; a < 9; a++) t[3 + a] = k.R[a];
+    float o[12];
+    wv::bcastn<12>(t, 6, o);
+#pragma unroll
+    for (int a = 0; a < 3; a++) tip[a] = o[a];
+#pragma unroll
+    for (int a = 0; a < 9; a++) Rt[a] = o[3 + a];
+}
+
+/* ---------------------------------------------------------------- */
+/* inverse kinematics: damped least squares on the 6 x 7 tip Jacobian,
+ * dq = J^T (J J^T + 0.5 I)^-1 e  ( == (J^T J + 0.5 I)^-1 J^T e of BussIK's
+ * CalcDeltaThetasDLS2), <= 40 iterations, stop on position residual.      */
+__device__ __forceinline__ void quat_from_R(const float* m, float* q)
+{
+    float tr = m[0] + m[4] + m[8];
+    if (tr > 0.f) {
+        float s = sqrtf(tr + 1.f);
+        q[3] = 0.5f * s;
+        s = 0.5f / s;
+        q[0] = (m[7] - m[5]) * s; q[1] = (m[2] - m[6]) * s; q[2] = (m[3] - m[1]) * s;
+    } else {
+        int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
+        int j = (i + 1) % 3, kk = (i + 2) % 3;
+        float s = sqrtf(m[4 * i] - m[4 * j] - m[4 * kk] + 1.f);
+        float t[4];
+        t[i] = 0.5f * s;
+        s = 0.5f / s;
+        t[3] = (m[3 * kk + j] - m[3 * j + kk]) * s;
+        t[j] = (m[3 * j + i] + m[3 * i + j]) * s;
+        t[kk] = (m[3 * kk + i] + m[3 * i + kk]) * s;
+        q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
+    }
+}
+
+/* solve the SPD system A y = b in place, A given by its 21 upper entries (row-major upper) */
+__device__ __forceinline__ void spd6_solve(float (*A)[6], float* b)
+{
+    /* Cholesky A = L L^T, L stored in the lower triangle */
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        float d = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[j][k] * A[j][k];
+        float inv = rsqrtf(d);
+        A[j][j] = inv; /* store 1/L_jj */
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            float s = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+            A[i][j] = s * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        float s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= A[i][k] * b[k];
+        b[i] = s * A[i][i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        float s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= A[k][i] * b[k];
+        b[i] = s * A[i][i];
+    }
+}
+
+__device__ __forceinline__ float ik_solve(const LaneConst& c, float q, const float* target)
+{
+    int l = wv::lane();
+    float diff = 1e30f;
+    for (int it = 0; it < IK_MAX_ITER && diff > IK_THRESHOLD; it++) {
+        Kin k;
+        fk(c, q, k);
+        float tip[3], Rt[9];
+        tip_frame(k, tip, Rt);
+        float e[6];
+#pragma unroll
+        for (int a = 0; a < 3; a++) e[a] = target[a] - tip[a];
+        diff = sqrtf(dot3(e, e));
+        /* orientation error towards the fixed tool quaternion [0,-1,0,0] (kuka.py:42):
+         * dq = tq * conj(sq) with tq = (0,-1,0,0)  ->  angle-axis */
+        float sq[4];
+        quat_from_R(Rt, sq);
+        /* tq * (-sx,-sy,-sz,sw), tq = (x=0,y=-1,z=0,w=0) */
+        float dx = sq[2], dy = -sq[3], dz = -sq[0], dw = -sq[1];
+        float vn = sqrtf(dx * dx + dy * dy + dz * dz);
+        float ang = 2.f * atan2f(vn, dw);
+        if (ang > 3.14159265358979f) ang -= 6.28318530717959f;
+        float sc = vn > 1e-12f ? ang / vn : 0.f;
+        e[3] = dx * sc; e[4] = dy * sc; e[5] = dz * sc;
+        /* Jacobian column of this lane's joint */
+        float col[6] = {0, 0, 0, 0, 0, 0};
+        if (l < 7) {
+            float r[3] = {tip[0] - k.p[0], tip[1] - k.p[1], tip[2] - k.p[2]};
+            cross3(k.S, r, col);
+            col[3] = k.S[0]; col[4] = k.S[1]; col[5] = k.S[2];
+        }
+        float A[6][6];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) {
+                float s = wv::sum_row0(col[a] * col[b]);
+                if (a == b) s += IK_DAMPING;
+                A[a][b] = s;
+                A[b][a] = s;
+            }
+        spd6_solve(A, e);
+        float dq = l < 7 ? dot6(col, e) : 0.f;
+        float mx = wv::max_row0(fabsf(dq));
+        if (mx > IK_MAX_STEP) dq *= IK_MAX_STEP / mx;
+        q += dq;
+    }
+    return q;
+}
+
+/* ---------------------------------------------------------------- */
+/* robot forward dynamics pieces                                      */
+struct Dyn {
+    float minv[NJ]; /* this lane's row of M^-1 */
+    float v[6];     /* spatial velocity of this link */
+};
+
+/* world-frame 10-parameter inertia of this lane's merged body */
+__device__ __forceinline__ void body_inertia(const LaneConst& c, const Kin& k, float* I10)
+{
+    float hw[3];
+    mat3v(k.R, c.h, hw);
+    const float* p = k.p;
+    float m = c.mass;
+    I10[0] = m;
+    I10[1] = m * p[0] + hw[0]; I10[2] = m * p[1] + hw[1]; I10[3] = m * p[2] + hw[2];
+    /* R Ilo R^T */
+    const float* R = k.R;
+    float T[9];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        T[3 * r] = R[3 * r] * c.ilo[0] + R[3 * r + 1] * c.ilo[1] + R[3 * r + 2] * c.ilo[2];
+        T[3 * r + 1] = R[3 * r] * c.ilo[1] + R[3 * r + 1] * c.ilo[3] + R[3 * r + 2] * c.ilo[4];
+        T[3 * r + 2] = R[3 * r] * c.ilo[2] + R[3 * r + 1] * c.ilo[4] + R[3 * r + 2] * c.ilo[5];
+    }
+    float I[6];
+    I[0] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
+    I[1] = T[0] * R[3] + T[1] * R[4] + T[2] * R[5];
+    I[2] = T[0] * R[6] + T[1] * R[7] + T[2] * R[8];
+    I[3] = T[3] * R[3] + T[4] * R[4] + T[5] * R[5];
+    I[4] = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+    I[5] = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+    /* shift link origin -> world origin: m[(p.p)1 - p p^T] + [2(p.hw)1 - p hw^T - hw p^T] */
+    float pp = dot3(p, p), ph = dot3(p, hw);
+    float dg = m * pp + 2.f * ph;
+    I10[4] = I[0] + dg - m * p[0] * p[0] - 2.f * p[0] * hw[0];
+    I10[5] = I[1] - m * p[0] * p[1] - p[0] * hw[1] - hw[0] * p[1];
+    I10[6] = I[2] - m * p[0] * p[2] - p[0] * hw[2] - hw[0] * p[2];
+    I10[7] = I[3] + dg - m * p[1] * p[1] - 2.f * p[1] * hw[1];
+    I10[8] = I[4] - m * p[1] * p[2] - p[1] * hw[2] - hw[1] * p[2];
+    I10[9] = I[5] + dg - m * p[2] * p[2] - 2.f * p[2] * hw[2];
+}
+
+/* M^-1 (this lane's row) by CRBA + in-place Gauss-Jordan; also returns own inertia */
+__device__ __forceinline__ void mass_inverse(const Kin& k, const float* I10, float* minv)
+{
+    int l = wv::lane();
+    float Ic[10];
+#pragma unroll
+    for (int a = 0; a < 10; a++) Ic[a] = chain_suffix(I10[a]);
+    float SF[12];
+#pragma unroll
+    for (int a = 0; a < 6; a++) SF[a] = k.S[a];
+    inertia_mul(Ic, k.S, SF + 6); /* F = Ic S */
+    float a[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        float o[12];
+        wv::bcastn<12>(SF, j, o);
+        bool related = !((l == 7 && j == 8) || (l == 8 && j == 7));
+        float lo = dot6(o, SF + 6); /* S_j . F_l   (j ancestor-or-self of l) */
+        float hi = dot6(SF, o + 6); /* S_l . F_j   (j descendant of l)        */
+        a[j] = related ? (j <= l ? lo : hi) : 0.f;
+    }
+    if (l >= NJ) { /* keep idle lanes finite: identity rows */
+#pragma unroll
+        for (int j = 0; j < NJ; j++) a[j] = 0.f;
+    }
+    /* in-place Gauss-Jordan inversion, lane = row, no pivoting (SPD) */
+#pragma unroll
+    for (int p = 0; p < NJ; p++) {
+        float piv[NJ];
+        wv::bcastn<NJ>(a, p, piv);
+        float d = 1.f / piv[p];
+        float f = a[p];
+        if (l == p) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) a[j] = piv[j] * d;
+            a[p] = d;
+        } else {
+            float fd = f * d;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) a[j] -= fd * piv[j];
+            a[p] = -fd;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) minv[j] = a[j];
+}
+
+/* bias torque h_l = S_l . sum_{subtree} (I a_b + v x* I v - f_ext) with gravity and Bullet's link damping */
+__device__ __forceinline__ float bias_torque(const LaneConst& c, const Kin& k, const float* I10, float qd, float* v_out)
+{
+    float s[6], v[6], cb[6], ab[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) s[a] = k.S[a] * qd;
+#pragma unroll
+    for (int a = 0; a < 6; a++) v[a] = chain_prefix(s[a]);
+    crm(v, s, cb);
+#pragma unroll
+    for (int a = 0; a < 6; a++) ab[a] = chain_prefix(cb[a]);
+    float f[6], hm[6], t[6];
+    inertia_mul(I10, ab, f);
+    inertia_mul(I10, v, hm);
+    crf(v, hm, t);
+#pragma unroll
+    for (int a = 0; a < 6; a++) f[a] += t[a];
+    /* gravity: force (0,0,-m g) at the COM -> [H x g ; m g] */
+    f[0] -= -GRAVITY * I10[2];
+    f[1] -= GRAVITY * I10[1];
+    f[5] -= -GRAVITY * I10[0];
+    /* link damping, angular: -(R Dsum R^T w) k (1+|w|) */
+    {
+        float wl[3], dw[3];
+        const float* R = k.R;
+        wl[0] = (R[0] * v[0] + R[3] * v[1] + R[6] * v[2]) * c.dsum[0];
+        wl[1] = (R[1] * v[0] + R[4] * v[1] + R[7] * v[2]) * c.dsum[1];
+        wl[2] = (R[2] * v[0] + R[5] * v[1] + R[8] * v[2]) * c.dsum[2];
+        mat3v(R, wl, dw);
+        float ka = LINK_DAMPING * (1.f + sqrtf(dot3(v, v)));
+        f[0] += dw[0] * ka; f[1] += dw[1] * ka; f[2] += dw[2] * ka;
+    }
+    /* link damping, linear, per massive sub-body at its own COM */
+#pragma unroll
+    for (int sb = 0; sb < 2; sb++) {
+        float cw[3], vc[3], fd[3], nd[3];
+        mat3v(k.R, c.sc[sb], cw);
+        cw[0] += k.p[0]; cw[1] += k.p[1]; cw[2] += k.p[2];
+        cross3(v, cw, vc);
+        vc[0] += v[3]; vc[1] += v[4]; vc[2] += v[5];
+        float kl = c.sm[sb] * LINK_DAMPING * (1.f + sqrtf(dot3(vc, vc)));
+        fd[0] = vc[0] * kl; fd[1] = vc[1] * kl; fd[2] = vc[2] * kl;
+        cross3(cw, fd, nd);
+        f[0] += nd[0]; f[1] += nd[1]; f[2] += nd[2];
+        f[3] += fd[0]; f[4] += fd[1]; f[5] += fd[2];
+    }
+    if (wv::lane() >= NJ) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) f[a] = 0.f;
+    }
+    float fc[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) fc[a] = chain_suffix(f[a]);
+#pragma unroll
+    for (int a = 0; a < 6; a++) v_out[a] = v[a];
+    return dot6(k.S, fc);
+}
+
+/* ---------------------------------------------------------------- */
+/* non-contact constraint rows (joint motors + joint limits), replicated in every lane */
+struct NcRows {
+    float dinv[NJ];      /* 1 / (M^-1)_dd */
+    float rhs_m[NJ];     /* motor rows */
+    float rhs_l[NJ];     /* limit rows */
+    float imp_m[NJ];     /* motor max impulse (0 = disabled) */
+    float app_m[NJ], app_l[NJ];
+    unsigned lim_active; /* bit d: limit row of dof d exists */
+    unsigned lim_upper;  /* bit d: it is the upper limit (Jacobian -1) */
+};
+
+__device__ __forceinline__ void build_nc_rows(const LaneConst& c, const float* minv, float q, float qd, float mtarget,
+                                              float mimp, NcRows& r)
+{
+    int l = wv::lane() < NJ ? wv::lane() : 0;
+    float den = minv[0];
+#pragma unroll
+    for (int j = 1; j < NJ; j++) den = (l == j) ? minv[j] : den;
+    float dinv = den > SIMD_EPS ? 1.f / den : 0.f;
+    /* btMultiBodyJointMotor: target velocity kp*(q*-q)/dt + qd + kd*(0-qd) */
+    float tv = ARM_KP * (mtarget - q) / DT + qd + ARM_KD * (0.f - qd);
+    float rm = (tv - qd) * dinv;
+    /* btMultiBodyJointLimitConstraint: active when (q-lo) <= 0 or (hi-q) <= 0 */
+    float plo = q - c.jlo, phi = c.jhi - q;
+    bool alo = plo <= 0.f, ahi = !alo && phi <= 0.f;
+    float pen = alo ? plo : phi;
+    float sg = alo ? 1.f : -1.f;
+    float rl = (-pen * JOINT_ERP / DT - sg * qd) * dinv;
+    bool valid = wv::lane() < NJ;
+    unsigned long long ma = wv::ballot(valid && (alo || ahi)), mu = wv::ballot(valid && ahi);
+    r.lim_active = (unsigned)ma & 0x1FFu;
+    r.lim_upper = (unsigned)mu & 0x1FFu;
+#pragma unroll
+    for (int d = 0; d < NJ; d++) {
+        float t[4] = {dinv, rm, rl, mimp}, o[4];
+        wv::bcastn<4>(t, d, o);
+        r.dinv[d] = o[0]; r.rhs_m[d] = o[1]; r.rhs_l[d] = o[2]; r.imp_m[d] = o[3];
+        r.app_m[d] = 0.f; r.app_l[d] = 0.f;
+    }
+}
+
+/* one Gauss-Seidel visit of a motor (kind 0) or limit (kind 1) row of dof D */
+template <int D>
+__device__ __forceinline__ void nc_row_solve(NcRows& r, int kind, const float* minv, float& dqd, float& resid)
+{
+    float dvd = wv::bcast(dqd, D);
+    float sg, rhs, lo, hi, app;
+    if (kind == 0) {
+        if (!(r.imp_m[D] > 0.f)) return;
+        sg = 1.f; rhs = r.rhs_m[D]; lo = -r.imp_m[D]; hi = r.imp_m[D]; app = r.app_m[D];
+    } else {
+        if (!((r.lim_active >> D) & 1u)) return;
+        sg = ((r.lim_upper >> D) & 1u) ? -1.f : 1.f; rhs = r.rhs_l[D]; lo = 0.f; hi = LIMIT_MAX_IMPULSE; app = r.app_l[D];
+    }
+    float delta = rhs - sg * dvd * r.dinv[D];
+    float sum = app + delta;
+    if (sum < lo) { delta = lo - app; app = lo; }
+    else if (sum > hi) { delta = hi - app; app = hi; }
+    else app = sum;
+    if (kind == 0) r.app_m[D] = app; else r.app_l[D] = app;
+    dqd += sg * minv[D] * delta;
+    float dv = r.dinv[D] != 0.f ? delta / r.dinv[D] : 0.f;
+    resid = fmaxf(resid, dv * dv);
+}
+
+/* rows in list order: motors (dof 2,3,0,1,4,7,8,5,6) then limits (same dof order);
+ * Bullet walks the list backwards on even iterations */
+__device__ __forceinline__ void nc_sweep(NcRows& r, bool forward, const float* minv, float& dqd, float& resid)
+{
+    if (forward) {
+        nc_row_solve<2>(r, 0, minv, dqd, resid); nc_row_solve<3>(r, 0, minv, dqd, resid); nc_row_solve<0>(r, 0, minv, dqd, resid);
+        nc_row_solve<1>(r, 0, minv, dqd, resid); nc_row_solve<4>(r, 0, minv, dqd, resid); nc_row_solve<7>(r, 0, minv, dqd, resid);
+        nc_row_solve<8>(r, 0, minv, dqd, resid); nc_row_solve<5>(r, 0, minv, dqd, resid); nc_row_solve<6>(r, 0, minv, dqd, resid);
+        nc_row_solve<2>(r, 1, minv, dqd, resid); nc_row_solve<3>(r, 1, minv, dqd, resid); nc_row_solve<0>(r, 1, minv, dqd, resid);
+        nc_row_solve<1>(r, 1, minv, dqd, resid); nc_row_solve<4>(r, 1, minv, dqd, resid); nc_row_solve<7>(r, 1, minv, dqd, resid);
+        nc_row_solve<8>(r, 1, minv, dqd, resid); nc_row_solve<5>(r, 1, minv, dqd, resid); nc_row_solve<6>(r, 1, minv, dqd, resid);
+    } else {
+        nc_row_solve<6>(r, 1, minv, dqd, resid); nc_row_solve<5>(r, 1, minv, dqd, resid); nc_row_solve<8>(r, 1, minv, dqd, resid);
+        nc_row_solve<7>(r, 1, minv, dqd, resid); nc_row_solve<4>(r, 1, minv, dqd, resid); nc_row_solve<1>(r, 1, minv, dqd, resid);
+        nc_row_solve<0>(r, 1, minv, dqd, resid); nc_row_solve<3>(r, 1, minv, dqd, resid); nc_row_solve<2>(r, 1, minv, dqd, resid);
+        nc_row_solve<6>(r, 0, minv, dqd, resid); nc_row_solve<5>(r, 0, minv, dqd, resid); nc_row_solve<8>(r, 0, minv, dqd, resid);
+        nc_row_solve<7>(r, 0, minv, dqd, resid); nc_row_solve<4>(r, 0, minv, dqd, resid); nc_row_solve<1>(r, 0, minv, dqd, resid);
+        nc_row_solve<0>(r, 0, minv, dqd, resid); nc_row_solve<3>(r, 0, minv, dqd, resid); nc_row_solve<2>(r, 0, minv, dqd, resid);
+    }
+}
+
+}  // namespace pmg
+#endif

@@ -1,0 +1,398 @@
+/*
+ * pmg_kernels.h -- per-environment step / reset bodies (one wavefront each).
+ * Included by pmg_kernels.hip (the gfx950 build) and by the test-only
+ * emulator translation unit.
+ */
+#ifndef PMG_KERNELS_H
+#define PMG_KERNELS_H
+
+#include "pmg_device.h"
+
+namespace pmg {
+
+struct EnvParams {
+    int n_envs, task, nb, grasping, has_obj, joint_control, binary_reward, max_steps, in_air, random_order;
+    int adim, odim, pdim, gdim, packed;
+    float thr;
+    float ee_lo[3], ee_hi[3];
+    float table_c[3], table_h[3], table_mu;
+    /* sampling boxes, kept in double so that the RNG draws reproduce numpy's float64 uniform() */
+    double tip_init[3], obj_lo[3], obj_hi[3], tgt_lo[3], tgt_hi[3], obj_z;
+    /* device arrays */
+    float* hot;      /* [N, HOT_DIM]  */
+    float* cold;     /* [N, COLD_DIM] */
+    float* goal;     /* [N, GOAL_DIM] */
+    float* blocks;   /* [N, BLOCK_DIM * nb] */
+    unsigned* rng;   /* [N, 625] MT19937 state + index */
+    float* out;      /* [N, packed]: obs | policy | ag | dg | reward | goal_achieved | done */
+};
+
+/* ------------------------------------------------------------------ */
+/* observation / reward pack                                           */
+/* single-step tasks: kuka_single_step_base_env.py:193-244; robot state: kuka.py:227-256 */
+__device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const LaneConst& c, float q, float qd,
+                                              int elapsed, bool with_reward)
+{
+    int l = wv::lane();
+    Kin k;
+    fk(c, q, k);
+    float tip[3], Rt[9];
+    tip_frame(k, tip, Rt);
+    /* spatial velocity of every link; lane 6 = link 7 (tip, gripper base), lane 7 = finger 1 */
+    float v[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) v[a] = chain_prefix(k.S[a] * qd);
+    float v6[6];
+    wv::bcastn<6>(v, 6, v6);
+    float tv[3], t[3];
+    cross3(v6, tip, t);
+    tv[0] = v6[3] + t[0]; tv[1] = v6[4] + t[1]; tv[2] = v6[5] + t[2];
+    float closeness = 0.f, fvel = 0.f;
+    if (P.grasping) {
+        /* tabs: finger frame origin -/+ 0.005 along finger y (urdf:480-494) */
+        float tab[3];
+        float sgn = l == 7 ? -0.005f : 0.005f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) tab[a] = k.p[a] + k.R[3 * a + 1] * sgn;
+        float vt[3];
+        cross3(v, tab, vt);
+        float pack[4] = {tab[0], tab[1], tab[2], v[4] + vt[1]}, t1[4], t2[4];
+        wv::bcastn<4>(pack, 7, t1);
+        wv::bcastn<4>(pack, 8, t2);
+        float d[3] = {t1[0] - t2[0], t1[1] - t2[1], t1[2] - t2[2]};
+        closeness = sqrtf(dot3(d, d));
+        /* gripper base origin: link 7 + 0.055 z (urdf:390-395) */
+        float gb[3] = {tip[0] + Rt[2] * (0.055f - TIP_Z), tip[1] + Rt[5] * (0.055f - TIP_Z), tip[2] + Rt[8] * (0.055f - TIP_Z)};
+        float vb[3];
+        cross3(v6, gb, vb);
+        fvel = (v6[4] + vb[1]) - t1[3];
+    }
+    float* o = P.out + (size_t)env * P.packed;
+    const float* g = P.goal + (size_t)env * GOAL_DIM;
+    int jo = P.joint_control ? 7 : 0;
+    float* obs = o;
+    float* pol = o + P.odim;
+    float* ag = pol + P.pdim;
+    float* dg = ag + P.gdim;
+    float* tail = dg + P.gdim;
+    if (jo && l < 7) { obs[l] = q; pol[l] = q; }
+    float agv[3] = {tip[0], tip[1], tip[2]};
+    if (P.task == PMG_TASK_REACH) {
+        if (l < 3) { float x = l == 0 ? tip[0] : (l == 1 ? tip[1] : tip[2]); obs[jo + l] = x; pol[jo + l] = x; ag[l] = x; }
+    } else if (P.task != PMG_TASK_BLOCK_STACK) {
+        const float* b = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
+        float bp[3] = {b[0], b[1], b[2]}, bv[3] = {b[7], b[8], b[9]}, bw[3] = {b[10], b[11], b[12]};
+        if (l == 0) {
+            float* s = obs + jo;
+            s[0] = tip[0]; s[1] = tip[1]; s[2] = tip[2];
+            s[3] = bp[0]; s[4] = bp[1]; s[5] = bp[2];
+            s[6] = closeness;
+            s[7] = tip[0] - bp[0]; s[8] = tip[1] - bp[1]; s[9] = tip[2] - bp[2];
+            s[10] = tv[0]; s[11] = tv[1]; s[12] = tv[2];
+            s[13] = fvel;
+            s[14] = tv[0] - bv[0]; s[15] = tv[1] - bv[1]; s[16] = tv[2] - bv[2];
+            s[17] = v6[0] - bw[0]; s[18] = v6[1] - bw[1]; s[19] = v6[2] - bw[2];
+            float* ps = pol + jo;
+            ps[0] = tip[0]; ps[1] = tip[1]; ps[2] = tip[2]; ps[3] = closeness;
+            ps[4] = tip[0] - bp[0]; ps[5] = tip[1] - bp[1]; ps[6] = tip[2] - bp[2];
+            ag[0] = bp[0]; ag[1] = bp[1]; ag[2] = bp[2];
+        }
+        agv[0] = bp[0]; agv[1] = bp[1]; agv[2] = bp[2];
+    } else {
+        /* block stack: kuka_multi_step_base_env.py:255-336, clipped to +-5 */
+        const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
+        if (l == 0) {
+            float* s = obs + jo;
+            s[0] = tip[0]; s[1] = tip[1]; s[2] = tip[2]; s[3] = closeness;
+            s[4] = tv[0]; s[5] = tv[1]; s[6] = tv[2]; s[7] = fvel;
+            float* ps = pol + jo;
+            ps[0] = tip[0]; ps[1] = tip[1]; ps[2] = tip[2]; ps[3] = closeness;
+        }
+        if (l < P.nb) {
+            const float* b = bb + BLOCK_DIM * l;
+            float* s = obs + jo + 8 + 16 * l;
+            float* ps = pol + jo + 4 + 3 * l;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                s[a] = b[a];
+                s[3 + a] = tip[a] - b[a];
+                ps[a] = tip[a] - b[a];
+                s[10 + a] = tv[a] - b[7 + a];
+                s[13 + a] = v6[a] - b[10 + a];
+                ag[3 * l + a] = b[a];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++) s[6 + a] = b[3 + a];
+        }
+    }
+    wv::lds_sync();
+    if (P.task == PMG_TASK_BLOCK_STACK) {
+        for (int i = l; i < P.odim; i += 64) obs[i] = fminf(fmaxf(obs[i], -5.f), 5.f);
+        for (int i = l; i < P.pdim; i += 64) pol[i] = fminf(fmaxf(pol[i], -5.f), 5.f);
+    }
+    if (l < P.gdim) dg[l] = g[l];
+    if (with_reward) {
+        /* _compute_reward: d = ||ag - dg||, binary -(d > thr) as float32 or dense -d */
+        float dd = 0.f;
+        if (P.task == PMG_TASK_BLOCK_STACK) {
+            const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
+            for (int i = 0; i < P.gdim; i++) { float e = bb[BLOCK_DIM * (i / 3) + i % 3] - g[i]; dd += e * e; }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; a++) { float e = agv[a] - g[a]; dd += e * e; }
+        }
+        float d = sqrtf(dd);
+        bool not_achieved = d > P.thr;
+        if (l == 0) {
+            tail[0] = P.binary_reward ? (not_achieved ? -1.f : -0.f) : -d;
+            tail[1] = not_achieved ? 0.f : 1.f;
+            tail[2] = elapsed >= P.max_steps ? 1.f : 0.f;
+        }
+    } else if (l == 0) {
+        tail[0] = 0.f; tail[1] = 0.f; tail[2] = 0.f;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* one 2 ms substep of the robot (no contacts in this path yet)         */
+__device__ __forceinline__ void robot_substep(const LaneConst& c, float& q, float& qd, float tau, float mtarget, float mimp)
+{
+    int l = wv::lane();
+    Kin k;
+    fk(c, q, k);
+    float I10[10], minv[NJ], v[6];
+    body_inertia(c, k, I10);
+    if (l >= NJ) {
+#pragma unroll
+        for (int a = 0; a < 10; a++) I10[a] = 0.f;
+    }
+    mass_inverse(k, I10, minv);
+    float h = bias_torque(c, k, I10, qd, v);
+    float rq = l < NJ ? tau - h : 0.f;
+    float qdd = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) qdd += minv[j] * wv::bcast(rq, j);
+    qd += DT * qdd;
+    NcRows r;
+    build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
+    float dqd = 0.f;
+    for (int it = 0; it < SOLVER_ITERS; it++) {
+        float resid = 0.f;
+        nc_sweep(r, (it & 1) != 0, minv, dqd, resid);
+        if (resid <= RESIDUAL_THRESHOLD) break;
+    }
+    qd += dqd;
+    q += DT * qd;
+}
+
+/* ------------------------------------------------------------------ */
+/* env.step(): kuka.py:167-225 + _get_obs + _compute_reward + TimeLimit */
+__device__ __forceinline__ void step_env(const EnvParams& P, const float* actions)
+{
+    int env = (int)blockIdx.x, l = wv::lane();
+    if (env >= P.n_envs) return;
+    LaneConst c;
+    load_lane_const(c);
+    float* hot = P.hot + (size_t)env * HOT_DIM;
+    int ll = l < NJ ? l : 0;
+    float q = hot[ll], qd = hot[9 + ll];
+    if (l >= NJ) { q = 0.f; qd = 0.f; }
+    const float* act = actions + (size_t)env * P.adim;
+    float grip = hot[28];
+    int elapsed = (int)hot[29];
+    if (P.grasping) grip = (float)(((double)act[P.adim - 1] + 1.0) * (0.035 / 2)); /* kuka.py:171 */
+    float mtarget = grip, mimp = FINGER_FORCE * PHYSICS_DT;
+    float ee[3] = {hot[18], hot[19], hot[20]};
+    float jt = l < 7 ? hot[21 + l] : 0.f;
+    if (P.joint_control) {
+        if (l < 7) jt = act[l] * 0.05f + jt; /* kuka.py:205 */
+        if (l < 7) mtarget = jt;
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {      /* kuka.py:209-212 */
+            float t = ee[a] + act[a] * 0.01f;
+            ee[a] = fminf(fmaxf(t, P.ee_lo[a]), P.ee_hi[a]);
+        }
+        float qik = ik_solve(c, q, ee);    /* kuka.py:214 */
+        if (l < 7) mtarget = qik;
+    }
+    if (l < 7) mimp = ARM_FORCE * PHYSICS_DT; /* kuka.py:282-290 */
+    for (int s = 0; s < SIM_STEPS; s++) {  /* kuka.py:223-225 */
+        float tau = -c.jdamp * qd;         /* joint damping latched per stepSimulation */
+        for (int ss = 0; ss < SUBSTEPS; ss++) robot_substep(c, q, qd, tau, mtarget, mimp);
+    }
+    elapsed++;
+    if (l < NJ) { hot[l] = q; hot[9 + l] = qd; }
+    if (l < 3) hot[18 + l] = l == 0 ? ee[0] : (l == 1 ? ee[1] : ee[2]);
+    if (l < 7) hot[21 + l] = jt;
+    if (l == 0) { hot[28] = grip; hot[29] = (float)elapsed; hot[30] = 1.f; }
+    write_outputs(P, env, c, q, qd, elapsed, true);
+}
+
+/* ------------------------------------------------------------------ */
+/* MT19937 exactly as numpy's RandomState (state in HBM, used by lane 0 only) */
+__device__ __forceinline__ unsigned mt_next(unsigned* mt)
+{
+    unsigned idx = mt[624];
+    if (idx >= 624u) {
+        int kk;
+        for (kk = 0; kk < 624 - 397; kk++) {
+            unsigned y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; kk < 623; kk++) {
+            unsigned y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        unsigned y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        idx = 0;
+    }
+    unsigned y = mt[idx];
+    mt[624] = idx + 1;
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ __forceinline__ double mt_uniform(unsigned* mt, double lo, double hi)
+{
+    unsigned a = mt_next(mt) >> 5, b = mt_next(mt) >> 6;
+    double u = (a * 67108864.0 + b) / 9007199254740992.0;
+    return lo + (hi - lo) * u;
+}
+__device__ __forceinline__ unsigned mt_interval(unsigned* mt, unsigned mx)
+{
+    if (mx == 0) return 0;
+    unsigned mask = mx;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    unsigned v;
+    while ((v = (mt_next(mt) & mask)) > mx) {}
+    return v;
+}
+
+/* task reset by lane 0: kuka_single_step_base_env.py:76-148, kuka_multi_step_base_env.py:221-250,
+ * kuka_multi_step_envs.py:34-87 */
+__device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
+{
+    unsigned* mt = P.rng + (size_t)env * 625;
+    float* g = P.goal + (size_t)env * GOAL_DIM;
+    float* cold = P.cold + (size_t)env * COLD_DIM;
+    float* blk = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
+    if (P.task != PMG_TASK_BLOCK_STACK) {
+        double center[3] = {P.tip_init[0], P.tip_init[1], P.tip_init[2]};
+        if (P.has_obj) {
+            double ox = P.tip_init[0], oy = P.tip_init[1];
+            for (;;) {
+                double dx = ox - P.tip_init[0], dy = oy - P.tip_init[1];
+                if (!(sqrt(dx * dx + dy * dy) < 0.1)) break;
+                ox = mt_uniform(mt, P.obj_lo[0], P.obj_hi[0]);
+                oy = mt_uniform(mt, P.obj_lo[1], P.obj_hi[1]);
+            }
+            blk[0] = (float)ox; blk[1] = (float)oy; blk[2] = (float)P.obj_z;
+            blk[3] = 0.f; blk[4] = 0.f; blk[5] = 0.f; blk[6] = 1.f;
+            for (int a = 7; a < 13; a++) blk[a] = 0.f;
+            center[0] = ox; center[1] = oy; center[2] = P.obj_z;
+        }
+        double gg[3];
+        for (;;) {
+            for (int a = 0; a < 3; a++) gg[a] = mt_uniform(mt, P.tgt_lo[a], P.tgt_hi[a]);
+            double dx = gg[0] - center[0], dy = gg[1] - center[1], dz = gg[2] - center[2];
+            if (sqrt(dx * dx + dy * dy + dz * dz) > 0.1) break;
+        }
+        if (!P.in_air) gg[2] = P.obj_z;
+        else if (P.grasping) {
+            if (mt_uniform(mt, 0.0, 1.0) >= 0.5) gg[2] = P.obj_z;
+        }
+        for (int a = 0; a < 3; a++) g[a] = (float)gg[a];
+    } else {
+        double bp[5][2];
+        for (int b = 0; b < P.nb; b++) {
+            for (;;) {
+                double x = mt_uniform(mt, P.obj_lo[0], P.obj_hi[0]);
+                double y = mt_uniform(mt, P.obj_lo[1], P.obj_hi[1]);
+                bool ok = true;
+                for (int cc = 0; cc < b; cc++) {
+                    double dx = x - bp[cc][0], dy = y - bp[cc][1];
+                    if (!(sqrt(dx * dx + dy * dy) > 0.06)) ok = false;
+                }
+                double dx = x - P.tip_init[0], dy = y - P.tip_init[1];
+                if (!(sqrt(dx * dx + dy * dy) > 0.06)) ok = false;
+                if (ok) { bp[b][0] = x; bp[b][1] = y; break; }
+            }
+        }
+        int order[5] = {0, 1, 2, 3, 4};
+        if (P.random_order)
+            for (int i = P.nb - 1; i >= 1; i--) {
+                unsigned j = mt_interval(mt, (unsigned)i);
+                int t = order[i]; order[i] = order[j]; order[j] = t;
+            }
+        double bx, by;
+        for (;;) {
+            bx = mt_uniform(mt, P.tgt_lo[0], P.tgt_hi[0]);
+            by = mt_uniform(mt, P.tgt_lo[1], P.tgt_hi[1]);
+            bool ok = true;
+            for (int cc = 0; cc < P.nb; cc++) {
+                double dx = bx - bp[cc][0], dy = by - bp[cc][1];
+                if (!(sqrt(dx * dx + dy * dy) > 0.08)) ok = false;
+            }
+            if (ok) break;
+        }
+        for (int b = 0; b < P.nb; b++) {
+            float* o = blk + BLOCK_DIM * b;
+            o[0] = (float)bp[b][0]; o[1] = (float)bp[b][1]; o[2] = 0.175f;
+            o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = 1.f;
+            for (int a = 7; a < 13; a++) o[a] = 0.f;
+        }
+        for (int b = 0; b < 5; b++) cold[8 + b] = (float)order[b];
+        cold[13] = (float)bx; cold[14] = (float)by; cold[15] = 0.175f;
+        for (int s = 0; s < P.nb; s++) {
+            int b = order[s];
+            g[3 * b] = (float)bx; g[3 * b + 1] = (float)by; g[3 * b + 2] = 0.175f + 0.03f * (float)s;
+        }
+    }
+}
+
+/* env.reset(): kuka.py:120-165 + the task reset above + _get_obs */
+__device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned char* mask)
+{
+    int env = (int)blockIdx.x, l = wv::lane();
+    if (env >= P.n_envs) return;
+    LaneConst c;
+    load_lane_const(c);
+    float* hot = P.hot + (size_t)env * HOT_DIM;
+    float* cold = P.cold + (size_t)env * COLD_DIM;
+    int ll = l < NJ ? l : 0;
+    bool doit = mask == nullptr || mask[env] != 0;
+    float q, qd;
+    int elapsed;
+    if (doit) {
+        q = l < 7 ? cold[l] : (l < NJ ? FINGER_LIMIT : 0.f); /* kuka.py:158,161 */
+        qd = 0.f;
+        float tgt[3] = {(float)P.tip_init[0], (float)P.tip_init[1], (float)P.tip_init[2]};
+        float qik = ik_solve(c, q, tgt);                       /* kuka.py:159 */
+        if (l < 7) { q = qik; cold[l] = qik; }                /* kuka.py:160 */
+        Kin k;
+        fk(c, q, k);
+        float tip[3], Rt[9];
+        tip_frame(k, tip, Rt);
+        if (l < NJ) { hot[l] = q; hot[9 + l] = 0.f; }
+        if (l < 3) hot[18 + l] = l == 0 ? tip[0] : (l == 1 ? tip[1] : tip[2]); /* kuka.py:163 */
+        if (l < 7) hot[21 + l] = q;                            /* kuka.py:165 */
+        if (l == 0) {
+            hot[28] = FINGER_LIMIT; hot[29] = 0.f; hot[30] = 0.f; hot[31] = hot[31] + 1.f;
+            task_reset_lane0(P, env);
+        }
+        elapsed = 0;
+        wv::lds_sync();
+    } else {
+        q = l < NJ ? hot[ll] : 0.f;
+        qd = l < NJ ? hot[9 + ll] : 0.f;
+        elapsed = (int)hot[29];
+    }
+    write_outputs(P, env, c, q, qd, elapsed, false);
+}
+
+}  // namespace pmg
+#endif

@@ -1,0 +1,11 @@
+/* pmg_launch.h -- host-callable launchers of the kernels in pmg_kernels.hip */
+#ifndef PMG_LAUNCH_H
+#define PMG_LAUNCH_H
+#include <hip/hip_runtime.h>
+#include "pmg_kernels.h"
+
+hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s);
+hipError_t pmg_launch_reset(const pmg::EnvParams& P, const unsigned char* d_mask, hipStream_t s);
+hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int G, float thr, int binary, float* reward,
+                             unsigned char* ok, hipStream_t s);
+#endif

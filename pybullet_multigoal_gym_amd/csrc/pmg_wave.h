@@ -1,0 +1,86 @@
+/*
+ * pmg_wave.h -- wavefront (64-lane) cross-lane primitives for gfx950 / CDNA4.
+ *
+ * One environment is simulated by one wavefront.  Lane l < 9 owns movable
+ * link / DoF l of the Kuka (iiwa_joint_1..7, finger1, finger2); all the small
+ * per-body reductions of the articulated-body maths are done with
+ *   - v_readlane_b32 broadcasts (bcast*): lane -> SGPR -> every lane,
+ *   - DPP row shifts inside the first 16-lane row (chain prefix / suffix sums),
+ *   - DPP butterfly + 4 readlanes for full-wave sums and maxima,
+ * never through memory.  (tests/emu/pmg_wave.h is the CPU stand-in the
+ * test-only emulator uses; this file is the only one that ships.)
+ */
+#ifndef PMG_WAVE_H
+#define PMG_WAVE_H
+
+#include <hip/hip_runtime.h>
+
+namespace wv {
+
+__device__ __forceinline__ int lane() { return (int)threadIdx.x; }
+
+/* wave-level LDS ordering: a single wavefront executes DS ops in order, the
+ * fence only stops the compiler from moving them (workgroup = one wave). */
+__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+
+/* value of lane `src` (wave-uniform) in every lane */
+__device__ __forceinline__ float bcast(float v, int src)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+template <int N>
+__device__ __forceinline__ void bcastn(const float* v, int src, float* out)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) out[k] = bcast(v[k], src);
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float old, float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+/* lane i <- lane i-N inside its 16-lane row, `fill` where there is no source */
+template <int N>
+__device__ __forceinline__ float row_shr(float v, float fill) { return dpp<0x110 + N>(fill, v); }
+/* lane i <- lane i+N inside its 16-lane row */
+template <int N>
+__device__ __forceinline__ float row_shl(float v, float fill) { return dpp<0x100 + N>(fill, v); }
+
+/* sum over each 16-lane row, result in every lane of the row */
+__device__ __forceinline__ float row_sum(float v)
+{
+    v += dpp<0xB1>(0.f, v);  /* quad_perm [1,0,3,2] */
+    v += dpp<0x4E>(0.f, v);  /* quad_perm [2,3,0,1] */
+    v += dpp<0x141>(0.f, v); /* row_half_mirror */
+    v += dpp<0x140>(0.f, v); /* row_mirror */
+    return v;
+}
+__device__ __forceinline__ float row_max(float v)
+{
+    v = fmaxf(v, dpp<0xB1>(v, v));
+    v = fmaxf(v, dpp<0x4E>(v, v));
+    v = fmaxf(v, dpp<0x141>(v, v));
+    v = fmaxf(v, dpp<0x140>(v, v));
+    return v;
+}
+/* sum over lanes 0..15 only (robot DoFs live there), uniform result */
+__device__ __forceinline__ float sum_row0(float v) { return bcast(row_sum(v), 0); }
+__device__ __forceinline__ float max_row0(float v) { return bcast(row_max(v), 0); }
+/* sum over all 64 lanes, uniform result */
+__device__ __forceinline__ float sum_all(float v)
+{
+    v = row_sum(v);
+    return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
+}
+__device__ __forceinline__ float max_all(float v)
+{
+    v = row_max(v);
+    return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
+}
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+
+}  // namespace wv
+#endif

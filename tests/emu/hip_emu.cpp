@@ -1,0 +1,69 @@
+/* hip_emu.cpp -- fiber scheduler of the SPMD emulator (TEST INFRASTRUCTURE, see hip_emu.h). */
+#include "hip_emu.h"
+
+#include <cstdio>
+
+emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
+float emu_xf[64 * 16];
+
+namespace {
+constexpr size_t STACK_BYTES = 512 * 1024;
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool done = false;
+};
+ucontext_t g_sched;
+std::vector<Fiber> g_fibers;
+int g_cur = -1;
+const std::function<void()>* g_body = nullptr;
+
+void trampoline()
+{
+    (*g_body)();
+    g_fibers[g_cur].done = true;
+    swapcontext(&g_fibers[g_cur].ctx, &g_sched);
+}
+}  // namespace
+
+void emu_barrier()
+{
+    /* yield to the scheduler; it resumes this fiber after every other live
+     * fiber of the block has run up to its own next barrier */
+    int me = g_cur;
+    swapcontext(&g_fibers[me].ctx, &g_sched);
+}
+
+void emu::launch(int grid, int block, const std::function<void()>& body)
+{
+    g_body = &body;
+    gridDim = {(unsigned)grid, 1, 1};
+    blockDim = {(unsigned)block, 1, 1};
+    if ((int)g_fibers.size() < block) g_fibers.resize(block);
+    for (int i = 0; i < block; i++)
+        if (!g_fibers[i].stack) g_fibers[i].stack = (char*)malloc(STACK_BYTES);
+    for (int b = 0; b < grid; b++) {
+        blockIdx = {(unsigned)b, 0, 0};
+        for (int i = 0; i < block; i++) {
+            Fiber& f = g_fibers[i];
+            f.done = false;
+            getcontext(&f.ctx);
+            f.ctx.uc_stack.ss_sp = f.stack;
+            f.ctx.uc_stack.ss_size = STACK_BYTES;
+            f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        bool alive = true;
+        while (alive) {
+            alive = false;
+            for (int i = 0; i < block; i++) {
+                if (g_fibers[i].done) continue;
+                g_cur = i;
+                threadIdx = {(unsigned)i, 0, 0};
+                swapcontext(&g_sched, &g_fibers[i].ctx);
+                if (!g_fibers[i].done) alive = true;
+            }
+        }
+    }
+    g_cur = -1;
+}

@@ -1,0 +1,107 @@
+/* CPU stand-in of pybullet_multigoal_gym_amd/csrc/pmg_wave.h for the fiber emulator
+ * (TEST INFRASTRUCTURE).  Same API, lane exchange through a shared buffer. */
+#ifndef PMG_WAVE_H
+#define PMG_WAVE_H
+#include "hip_emu.h"
+
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+
+namespace wv {
+inline int lane() { return (int)threadIdx.x; }
+inline void lds_sync() { emu_barrier(); }
+
+template <int N>
+inline void exchange_put(const float* v)
+{
+    for (int k = 0; k < N; k++) emu_xf[64 * k + lane()] = v[k];
+    emu_barrier();
+}
+inline void exchange_done() { emu_barrier(); }
+
+template <int N>
+inline void bcastn(const float* v, int src, float* out)
+{
+    exchange_put<N>(v);
+    float t[N];
+    for (int k = 0; k < N; k++) t[k] = emu_xf[64 * k + src];
+    exchange_done();
+    for (int k = 0; k < N; k++) out[k] = t[k];
+}
+inline float bcast(float v, int src)
+{
+    float o;
+    bcastn<1>(&v, src, &o);
+    return o;
+}
+inline int bcast_i(int v, int src) { return __float_as_int(bcast(__int_as_float(v), src)); }
+
+template <class F>
+inline float permute(float v, float fill, F srcfn)
+{
+    exchange_put<1>(&v);
+    int s = srcfn(lane());
+    float r = s >= 0 ? emu_xf[s] : fill;
+    exchange_done();
+    return r;
+}
+template <int N>
+inline float row_shr(float v, float fill)
+{
+    return permute(v, fill, [](int l) { return (l & 15) >= N ? l - N : -1; });
+}
+template <int N>
+inline float row_shl(float v, float fill)
+{
+    return permute(v, fill, [](int l) { return (l & 15) + N <= 15 ? l + N : -1; });
+}
+inline float row_sum(float v)
+{
+    exchange_put<1>(&v);
+    float s = 0;
+    int b = lane() & ~15;
+    /* same association order as the DPP butterfly: ((a+b)+(c+d)) pairs, then halves */
+    float q[4];
+    for (int g = 0; g < 4; g++) {
+        float a = emu_xf[b + 4 * g], bb = emu_xf[b + 4 * g + 1], c = emu_xf[b + 4 * g + 2], d = emu_xf[b + 4 * g + 3];
+        q[g] = (a + bb) + (c + d);
+    }
+    s = (q[0] + q[1]) + (q[2] + q[3]);
+    exchange_done();
+    return s;
+}
+inline float row_max(float v)
+{
+    exchange_put<1>(&v);
+    int b = lane() & ~15;
+    float s = emu_xf[b];
+    for (int k = 1; k < 16; k++) s = fmaxf(s, emu_xf[b + k]);
+    exchange_done();
+    return s;
+}
+inline float sum_row0(float v) { return bcast(row_sum(v), 0); }
+inline float max_row0(float v) { return bcast(row_max(v), 0); }
+inline float sum_all(float v)
+{
+    v = row_sum(v);
+    float t[4] = {bcast(v, 0), bcast(v, 16), bcast(v, 32), bcast(v, 48)};
+    return (t[0] + t[1]) + (t[2] + t[3]);
+}
+inline float max_all(float v)
+{
+    v = row_max(v);
+    return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
+}
+inline unsigned long long ballot(bool p)
+{
+    float f = p ? 1.f : 0.f;
+    exchange_put<1>(&f);
+    unsigned long long m = 0;
+    for (int k = 0; k < 64; k++)
+        if (emu_xf[k] != 0.f) m |= 1ull << k;
+    exchange_done();
+    return m;
+}
+}  // namespace wv
+#endif

@@ -284,6 +284,29 @@ def main():
     H.append('#define PMG_SUB_MASS ' + arr(sm))
     H.append('#define PMG_SUB_COM ' + arr(sc) + '   /* in the movable link frame */')
     H.append('#define PMG_SUB_INERTIA ' + arr(si) + '   /* principal, link-aligned, about the sub-body COM */')
+    # ---- merged movable bodies (what the HIP kernels use): fixed children folded in ----
+    mb_mass, mb_h, mb_ilo, mb_dsum, mb_sm, mb_sc = [], [], [], [], [], []
+    for m in mov_link:
+        M = 0.0; h = np.zeros(3); I = np.zeros((3, 3)); D = np.zeros(3); sm = []; scs = []
+        for x in sub[m]:
+            l = np.array(x['com']); ms = x['mass']
+            M += ms; h += ms * l
+            I += np.diag(x['inertia']) + ms * (l @ l * np.eye(3) - np.outer(l, l))
+            D += np.array(x['inertia'])
+            if ms > 0:
+                sm.append(ms); scs.append(l.tolist())
+        assert len(sm) <= 2
+        while len(sm) < 2:
+            sm.append(0.0); scs.append([0.0, 0.0, 0.0])
+        mb_mass.append(M); mb_h.append(h.tolist())
+        mb_ilo.append([I[0, 0], I[0, 1], I[0, 2], I[1, 1], I[1, 2], I[2, 2]])
+        mb_dsum.append(D.tolist()); mb_sm.append(sm); mb_sc.append(scs)
+    H.append('#define PMG_MB_MASS ' + arr(mb_mass) + '   /* merged movable bodies */')
+    H.append('#define PMG_MB_H ' + arr(mb_h) + '   /* first moment sum(m_s l_s), link frame */')
+    H.append('#define PMG_MB_ILO ' + arr(mb_ilo) + '   /* inertia about the link origin, link axes: xx xy xz yy yz zz */')
+    H.append('#define PMG_MB_DSUM ' + arr(mb_dsum) + '   /* sum of sub-body principal inertias (angular damping) */')
+    H.append('#define PMG_MB_SUBM_MASS ' + arr(mb_sm) + '   /* massive sub-bodies (linear damping) */')
+    H.append('#define PMG_MB_SUBM_COM ' + arr(mb_sc))
     H.append('#define PMG_TIP_OFF ' + arr(model['tip_off']) + '   /* iiwa_gripper_tip in link_7 frame */')
     H.append('#define PMG_GBASE_OFF ' + arr(model['gbase_off']))
     H.append('#define PMG_TAB1_OFF ' + arr(model['tab1_off']) + '   /* in finger1 frame */')
