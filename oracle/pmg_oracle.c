@@ -61,7 +61,9 @@ typedef double real;
 #define JOINT_ERP ((real)0.2)          /* [BULLET-PRIOR] btContactSolverInfo::m_erp default */
 #define LINEAR_SLOP ((real)1e-5)       /* [BULLET-PRIOR] PyBullet createEmptyDynamicsWorld */
 #define RESIDUAL_THRESHOLD ((real)1e-7)/* [BULLET-PRIOR] m_leastSquaresResidualThreshold */
+#ifndef LINK_DAMPING
 #define LINK_DAMPING ((real)0.04)      /* [BULLET-PRIOR] btMultiBody m_linearDamping/m_angularDamping */
+#endif
 #define LIMIT_MAX_IMPULSE ((real)100.0)/* [BULLET-PRIOR] btMultiBodyConstraint m_maxAppliedImpulse */
 #define ARM_KP ((real)0.03)            /* kuka.py:289 */
 #define ARM_KD ((real)1.0)             /* kuka.py:290 */

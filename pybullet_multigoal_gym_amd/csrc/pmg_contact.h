@@ -1,0 +1,457 @@
+/*
+ * pmg_contact.h -- contacts of the batched env: box-box narrowphase (one pair
+ * per lane), contact/friction constraint rows staged in LDS, and the
+ * sequential-impulse visit of one row executed by the whole wavefront
+ * (lane = DoF: lanes 0..8 robot joints, lanes 16+8b+c component c of block b).
+ *
+ * Restates, per env, what Bullet does inside stepSimulation for the pairs
+ * that can touch in the reference's tasks: table x
+ * block, block x block, finger x block, finger x table; rows and solver order
+ * as in the oracle (oracle/pmg_oracle.c "collide", "row_setup", "substep").
+ */
+#ifndef PMG_CONTACT_H
+#define PMG_CONTACT_H
+
+#include "pmg_device.h"
+
+namespace pmg {
+
+constexpr float CONTACT_MARGIN = 0.002f;
+constexpr float EDGE_FUDGE = 1.05f;
+constexpr float BLOCK_MASS = (float)PMG_BLOCK_MASS;
+constexpr float BLOCK_INERTIA = 0.0009f;      /* isotropic cube: PMG_BLOCK_INERTIA */
+constexpr float BLOCK_HALF = 0.015f;
+constexpr float FINGER_RADIUS = 0.0431f;      /* bounding sphere of the finger box + slack (oracle cull) */
+constexpr int ROW_STRIDE = 40;                /* floats per constraint row in LDS */
+/* row layout: [0..8] J robot, [9..14] J block slot A, [15..20] J block slot B, [21..23] pad,
+ *             [24..32] M^-1 J^T robot, [33] dinv, [34] rhs, [35] mu (friction rows), [36] applied,
+ *             [37] block id A (or -1), [38] block id B (or -1), [39] has_robot */
+
+struct BoxPose { float c[3]; float R[9]; };
+
+struct CPoint { float pa[3], pb[3], n[3], dist; };
+
+__device__ __forceinline__ int clip_poly(const float (*in)[2], int n, float (*out)[2], int axis, float sign, float lim)
+{
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        const float* a = in[i];
+        const float* b = in[(i + 1) % n];
+        float da = sign * a[axis] - lim, db = sign * b[axis] - lim;
+        if (da <= 0.f) { out[m][0] = a[0]; out[m][1] = a[1]; m++; }
+        if ((da < 0.f && db > 0.f) || (da > 0.f && db < 0.f)) {
+            float t = da / (da - db);
+            out[m][0] = a[0] + t * (b[0] - a[0]);
+            out[m][1] = a[1] + t * (b[1] - a[1]);
+            m++;
+        }
+    }
+    return m;
+}
+
+/* SAT over the 15 axes + face clipping / edge-edge; <= 4 points; n points from B to A */
+__device__ inline int box_box(const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb,
+                              const float* hb, float margin, CPoint* out)
+{
+    float A[3][3], B[3][3];
+    for (int i = 0; i < 3; i++)
+        for (int a = 0; a < 3; a++) { A[i][a] = Ra[3 * a + i]; B[i][a] = Rb[3 * a + i]; }
+    float d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+    float C[3][3], Q[3][3], dA[3], dB[3];
+    for (int i = 0; i < 3; i++) {
+        dA[i] = dot3(d, A[i]);
+        dB[i] = dot3(d, B[i]);
+        for (int j = 0; j < 3; j++) { C[i][j] = dot3(A[i], B[j]); Q[i][j] = fabsf(C[i][j]); }
+    }
+    float best = -1e30f;
+    int code = -1;
+    float nrm[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; i++) {
+        float s = fabsf(dA[i]) - (ha[i] + hb[0] * Q[i][0] + hb[1] * Q[i][1] + hb[2] * Q[i][2]);
+        if (s > margin) return 0;
+        if (s > best) { best = s; code = i; float sg = dA[i] < 0.f ? -1.f : 1.f; nrm[0] = sg * A[i][0]; nrm[1] = sg * A[i][1]; nrm[2] = sg * A[i][2]; }
+    }
+    for (int j = 0; j < 3; j++) {
+        float s = fabsf(dB[j]) - (hb[j] + ha[0] * Q[0][j] + ha[1] * Q[1][j] + ha[2] * Q[2][j]);
+        if (s > margin) return 0;
+        if (s > best) { best = s; code = 3 + j; float sg = dB[j] < 0.f ? -1.f : 1.f; nrm[0] = sg * B[j][0]; nrm[1] = sg * B[j][1]; nrm[2] = sg * B[j][2]; }
+    }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            float L[3];
+            cross3(A[i], B[j], L);
+            float len = sqrtf(dot3(L, L));
+            if (len < 1e-6f) continue;
+            float proj = dot3(d, L);
+            float ra = ha[i1] * Q[i2][j] + ha[i2] * Q[i1][j];
+            float rb = hb[j1] * Q[i][j2] + hb[j2] * Q[i][j1];
+            float s = (fabsf(proj) - (ra + rb)) / len;
+            if (s > margin) return 0;
+            float pen = s < 0.f ? s * EDGE_FUDGE : s / EDGE_FUDGE;
+            if (pen > best) {
+                best = s; code = 6 + 3 * i + j;
+                float sg = proj < 0.f ? -1.f : 1.f;
+                nrm[0] = sg * L[0] / len; nrm[1] = sg * L[1] / len; nrm[2] = sg * L[2] / len;
+            }
+        }
+    if (code < 0) return 0;
+    if (code >= 6) {
+        int i = (code - 6) / 3, j = (code - 6) % 3;
+        float pa[3] = {ca[0], ca[1], ca[2]}, pb[3] = {cb[0], cb[1], cb[2]};
+        for (int kx = 0; kx < 3; kx++) {
+            if (kx != i) { float sg = dot3(nrm, A[kx]) > 0.f ? 1.f : -1.f; for (int a = 0; a < 3; a++) pa[a] += sg * ha[kx] * A[kx][a]; }
+            if (kx != j) { float sg = dot3(nrm, B[kx]) > 0.f ? -1.f : 1.f; for (int a = 0; a < 3; a++) pb[a] += sg * hb[kx] * B[kx][a]; }
+        }
+        float r[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+        float uaub = C[i][j], q1 = dot3(A[i], r), q2 = -dot3(B[j], r);
+        float den = 1.f - uaub * uaub;
+        float s = 0.f, t = 0.f;
+        if (den > 1e-8f) { s = (q1 + uaub * q2) / den; t = (uaub * q1 + q2) / den; }
+        for (int a = 0; a < 3; a++) {
+            out[0].pa[a] = pa[a] + s * A[i][a];
+            out[0].pb[a] = pb[a] + t * B[j][a];
+            out[0].n[a] = -nrm[a];
+        }
+        out[0].dist = best;
+        return 1;
+    }
+    bool refA = code < 3;
+    const float *cr = refA ? ca : cb, *ci = refA ? cb : ca, *hr = refA ? ha : hb, *hi = refA ? hb : ha;
+    float (*Rr)[3] = refA ? A : B;
+    float (*Ri)[3] = refA ? B : A;
+    int ax = refA ? code : code - 3;
+    float nr[3];
+    if (refA) { nr[0] = nrm[0]; nr[1] = nrm[1]; nr[2] = nrm[2]; } else { nr[0] = -nrm[0]; nr[1] = -nrm[1]; nr[2] = -nrm[2]; }
+    int ia = 0;
+    float bestd = -1.f;
+    for (int kx = 0; kx < 3; kx++) {
+        float dd = fabsf(dot3(nr, Ri[kx]));
+        if (dd > bestd) { bestd = dd; ia = kx; }
+    }
+    float isg = dot3(nr, Ri[ia]) > 0.f ? -1.f : 1.f;
+    int iu = (ia + 1) % 3, iv = (ia + 2) % 3, ru = (ax + 1) % 3, rv = (ax + 2) % 3;
+    float fc[3];
+    for (int a = 0; a < 3; a++) fc[a] = ci[a] + isg * hi[ia] * Ri[ia][a];
+    float poly[8][2], tmp[8][2], vz[4];
+    const float SU[4] = {1.f, -1.f, -1.f, 1.f}, SV[4] = {1.f, 1.f, -1.f, -1.f};
+    for (int c = 0; c < 4; c++) {
+        float rel[3];
+        for (int a = 0; a < 3; a++) rel[a] = fc[a] + SU[c] * hi[iu] * Ri[iu][a] + SV[c] * hi[iv] * Ri[iv][a] - cr[a];
+        poly[c][0] = dot3(rel, Rr[ru]);
+        poly[c][1] = dot3(rel, Rr[rv]);
+        vz[c] = dot3(rel, nr);
+    }
+    float e1u = poly[1][0] - poly[0][0], e1v = poly[1][1] - poly[0][1], e1z = vz[1] - vz[0];
+    float e2u = poly[3][0] - poly[0][0], e2v = poly[3][1] - poly[0][1], e2z = vz[3] - vz[0];
+    float det = e1u * e2v - e1v * e2u;
+    float gu = 0.f, gv = 0.f;
+    if (fabsf(det) > 1e-12f) { gu = (e1z * e2v - e2z * e1v) / det; gv = (e2z * e1u - e1z * e2u) / det; }
+    float z0 = vz[0] - gu * poly[0][0] - gv * poly[0][1];
+    int n = 4;
+    n = clip_poly(poly, n, tmp, 0, 1.f, hr[ru]);
+    n = clip_poly(tmp, n, poly, 0, -1.f, hr[ru]);
+    n = clip_poly(poly, n, tmp, 1, 1.f, hr[rv]);
+    n = clip_poly(tmp, n, poly, 1, -1.f, hr[rv]);
+    float pts[8][3], sep[8];
+    int m = 0;
+    for (int c = 0; c < n; c++) {
+        float z = z0 + gu * poly[c][0] + gv * poly[c][1];
+        float s = z - hr[ax];
+        if (s > margin) continue;
+        pts[m][0] = poly[c][0]; pts[m][1] = poly[c][1]; pts[m][2] = z;
+        sep[m] = s;
+        m++;
+    }
+    if (m == 0) return 0;
+    int sel[4], ns = 0;
+    if (m <= 4) {
+        for (int c = 0; c < m; c++) sel[ns++] = c;
+    } else {
+        int i0 = 0;
+        for (int c = 1; c < m; c++) if (sep[c] < sep[i0]) i0 = c;
+        int i1 = -1; float bd = -1.f;
+        for (int c = 0; c < m; c++) {
+            if (c == i0) continue;
+            float du = pts[c][0] - pts[i0][0], dv = pts[c][1] - pts[i0][1];
+            float dd = du * du + dv * dv;
+            if (dd > bd) { bd = dd; i1 = c; }
+        }
+        int i2 = -1, i3 = -1; float amax = 0.f, amin = 0.f;
+        for (int c = 0; c < m; c++) {
+            if (c == i0 || c == i1) continue;
+            float ar = (pts[i1][0] - pts[i0][0]) * (pts[c][1] - pts[i0][1]) - (pts[i1][1] - pts[i0][1]) * (pts[c][0] - pts[i0][0]);
+            if (ar > amax) { amax = ar; i2 = c; }
+            if (ar < amin) { amin = ar; i3 = c; }
+        }
+        sel[ns++] = i0; sel[ns++] = i1;
+        if (i2 >= 0) sel[ns++] = i2;
+        if (i3 >= 0) sel[ns++] = i3;
+    }
+    for (int c = 0; c < ns; c++) {
+        int s = sel[c];
+        float pin[3], pref[3];
+        for (int a = 0; a < 3; a++) {
+            float base = cr[a] + pts[s][0] * Rr[ru][a] + pts[s][1] * Rr[rv][a];
+            pin[a] = base + pts[s][2] * nr[a];
+            pref[a] = base + hr[ax] * nr[a];
+        }
+        for (int a = 0; a < 3; a++) {
+            if (refA) { out[c].pa[a] = pref[a]; out[c].pb[a] = pin[a]; out[c].n[a] = -nr[a]; }
+            else { out[c].pa[a] = pin[a]; out[c].pb[a] = pref[a]; out[c].n[a] = nr[a]; }
+        }
+        out[c].dist = sep[s];
+    }
+    return ns;
+}
+
+/* [BULLET-PRIOR] btPlaneSpace1 */
+__device__ __forceinline__ void plane_space(const float* n, float* p, float* q)
+{
+    if (fabsf(n[2]) > 0.7071067811865475244f) {
+        float a = n[1] * n[1] + n[2] * n[2];
+        float k = 1.f / sqrtf(a);
+        p[0] = 0.f; p[1] = -n[2] * k; p[2] = n[1] * k;
+        q[0] = a * k; q[1] = -n[0] * p[2]; q[2] = n[0] * p[1];
+    } else {
+        float a = n[0] * n[0] + n[1] * n[1];
+        float k = 1.f / sqrtf(a);
+        p[0] = -n[1] * k; p[1] = n[0] * k; p[2] = 0.f;
+        q[0] = -n[2] * p[1]; q[1] = n[2] * p[0]; q[2] = a * k;
+    }
+}
+
+__device__ __forceinline__ void quat_to_R(const float* q, float* R)
+{
+    float x = q[0], y = q[1], z = q[2], w = q[3];
+    float d = x * x + y * y + z * z + w * w;
+    float s = 2.f / d;
+    float xs = x * s, ys = y * s, zs = z * s;
+    float wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys, xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    R[0] = 1.f - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+    R[3] = xy + wz; R[4] = 1.f - (xx + zz); R[5] = yz - wx;
+    R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.f - (xx + yy);
+}
+
+/* body ids in contacts */
+constexpr int BODY_STATIC = -1;
+constexpr int BODY_FINGER1 = 5, BODY_FINGER2 = 6; /* blocks are 0..4 */
+
+/* per-env LDS of the contact path */
+template <int NB, int MAXC>
+struct ContactLds {
+    static constexpr int NPAIR = NB + NB * (NB - 1) / 2 + 2 * (NB + 1);
+    float blk[NB > 0 ? NB : 1][BLOCK_DIM];    /* pos3 quat4 vel3 omg3 (persistent over the substeps) */
+    float blkR[NB > 0 ? NB : 1][9];
+    float fing[2][12];                         /* finger box centre + rotation */
+    float S[NJ][6];
+    float qd[NJ];
+    float minv[NJ][NJ];
+    int pair_count[NPAIR];
+    float stage[NPAIR][4][10];                 /* pa pb n dist per staged point */
+    float con[MAXC][12];                       /* a b pa3 pb3 n3 dist -> [0]=a [1]=b [2..4]pa [5..7]pb [8..10]n [11]dist */
+    float con_mu[MAXC];
+    float rows[3 * MAXC][ROW_STRIDE];
+    int ncon;
+};
+
+template <int NB>
+__device__ __forceinline__ void decode_pair(int i, int nb, int& a, int& b)
+{
+    /* order: block x table | block x block (b < c) | finger f: blocks..., table */
+    if (i < nb) { a = i; b = BODY_STATIC; return; }
+    i -= nb;
+    int nbb = nb * (nb - 1) / 2;
+    if (i < nbb) {
+        int x = 0;
+        for (int p = 0; p < nb; p++)
+            for (int q2 = p + 1; q2 < nb; q2++) {
+                if (x == i) { a = p; b = q2; return; }
+                x++;
+            }
+    }
+    i -= nbb;
+    int f = i / (nb + 1), r = i % (nb + 1);
+    a = f == 0 ? BODY_FINGER1 : BODY_FINGER2;
+    b = r < nb ? r : BODY_STATIC;
+}
+
+/* collision detection for every candidate pair of this env; fills L.con / L.ncon (uniform) */
+template <int NB, int MAXC>
+__device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const float* table_c, const float* table_h, float table_mu)
+{
+    using LT = ContactLds<NB, MAXC>;
+    int l = wv::lane();
+    int npair = nb + nb * (nb - 1) / 2 + 2 * (nb + 1);
+    const float I3[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
+    const float fh[3] = PMG_FINGER_HALF;
+    const float bh[3] = {BLOCK_HALF, BLOCK_HALF, BLOCK_HALF};
+    for (int i = l; i < npair; i += 64) {
+        int a, b;
+        decode_pair<NB>(i, nb, a, b);
+        const float *ca, *Ra, *ha, *cb, *Rb, *hb;
+        float tc[3] = {table_c[0], table_c[1], table_c[2]}, th[3] = {table_h[0], table_h[1], table_h[2]};
+        if (a >= BODY_FINGER1) { ca = L.fing[a - BODY_FINGER1]; Ra = L.fing[a - BODY_FINGER1] + 3; ha = fh; }
+        else { ca = L.blk[a]; Ra = L.blkR[a]; ha = bh; }
+        bool cull = false;
+        if (b == BODY_STATIC) {
+            cb = tc; Rb = I3; hb = th;
+            if (a >= BODY_FINGER1) cull = !(ca[2] - FINGER_RADIUS < tc[2] + th[2] + CONTACT_MARGIN);
+        } else {
+            cb = L.blk[b]; Rb = L.blkR[b]; hb = bh;
+            float dd[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+            float lim = a >= BODY_FINGER1 ? 0.075f : 0.06f;
+            cull = dot3(dd, dd) > lim * lim;
+        }
+        int n = 0;
+        if (!cull) {
+            CPoint cp[4];
+            n = box_box(ca, Ra, ha, cb, Rb, hb, CONTACT_MARGIN, cp);
+            for (int c = 0; c < n; c++) {
+                float* o = L.stage[i][c];
+                for (int k = 0; k < 3; k++) { o[k] = cp[c].pa[k]; o[3 + k] = cp[c].pb[k]; o[6 + k] = cp[c].n[k]; }
+                o[9] = cp[c].dist;
+            }
+        }
+        L.pair_count[i] = n;
+    }
+    wv::lds_sync();
+    int total = 0;
+    for (int i = l; i < npair; i += 64) {
+        int off = 0;
+        for (int j = 0; j < i; j++) off += L.pair_count[j];
+        int n = L.pair_count[i];
+        int a, b;
+        decode_pair<NB>(i, nb, a, b);
+        float mu = (a >= BODY_FINGER1 ? (float)PMG_FINGER_FRICTION : (float)PMG_BLOCK_FRICTION) *
+                   (b == BODY_STATIC ? table_mu : (float)PMG_BLOCK_FRICTION);
+        for (int c = 0; c < n && off + c < MAXC; c++) {
+            float* o = L.con[off + c];
+            const float* s = L.stage[i][c];
+            o[0] = (float)a; o[1] = (float)b;
+            for (int k = 0; k < 10; k++) o[2 + k] = s[k];
+            L.con_mu[off + c] = mu;
+        }
+    }
+    for (int j = 0; j < npair; j++) total += L.pair_count[j];
+    if (total > MAXC) total = MAXC;
+    wv::lds_sync();
+    (void)sizeof(LT);
+    return total;
+}
+
+/* Jacobian entries of one contact direction; writes one LDS row and returns rel. velocity */
+template <int NB, int MAXC>
+__device__ __forceinline__ float row_setup(ContactLds<NB, MAXC>& L, float* row, int a, int b, const float* pa, const float* pb,
+                                           const float* dir)
+{
+    for (int k = 0; k < ROW_STRIDE; k++) row[k] = 0.f;
+    row[37] = -1.f; row[38] = -1.f;
+    float denom = 0.f, rel = 0.f;
+    bool has_robot = false;
+    for (int s = 0; s < 2; s++) {
+        float sg = s == 0 ? 1.f : -1.f;
+        int id = s == 0 ? a : b;
+        const float* pt = s == 0 ? pa : pb;
+        if (id == BODY_STATIC) continue;
+        if (id >= BODY_FINGER1) {
+            int own = id == BODY_FINGER1 ? 7 : 8;
+            for (int d = 0; d < NJ; d++) {
+                if (d >= 7 && d != own) continue;
+                const float* S = L.S[d];
+                float v[3];
+                cross3(S, pt, v);
+                v[0] += S[3]; v[1] += S[4]; v[2] += S[5];
+                row[d] += sg * dot3(v, dir);
+            }
+            has_robot = true;
+        } else {
+            const float* bl = L.blk[id];
+            float r[3] = {pt[0] - bl[0], pt[1] - bl[1], pt[2] - bl[2]}, rxn[3];
+            cross3(r, dir, rxn);
+            float* J = row + 9 + 6 * s;
+            for (int k = 0; k < 3; k++) { J[k] = sg * dir[k]; J[3 + k] = sg * rxn[k]; }
+            row[37 + s] = (float)id;
+            denom += dot3(J, J) / BLOCK_MASS + dot3(J + 3, J + 3) / BLOCK_INERTIA;
+            rel += dot3(J, bl + 7) + dot3(J + 3, bl + 10);
+        }
+    }
+    if (has_robot) {
+        for (int i = 0; i < NJ; i++) {
+            float s = 0.f;
+            for (int j = 0; j < NJ; j++) s += L.minv[i][j] * row[j];
+            row[24 + i] = s;
+        }
+        for (int d = 0; d < NJ; d++) { denom += row[d] * row[24 + d]; rel += row[d] * L.qd[d]; }
+        row[39] = 1.f;
+    }
+    row[33] = denom > SIMD_EPS ? 1.f / denom : 0.f;
+    return rel;
+}
+
+/* build the normal + 2 friction rows of every contact (lane = contact) */
+template <int NB, int MAXC>
+__device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int nc)
+{
+    int l = wv::lane();
+    for (int c = l; c < nc; c += 64) {
+        const float* o = L.con[c];
+        int a = (int)o[0], b = (int)o[1];
+        float pa[3] = {o[2], o[3], o[4]}, pb[3] = {o[5], o[6], o[7]}, n[3] = {o[8], o[9], o[10]};
+        float* rn = L.rows[c];
+        float rel = row_setup(L, rn, a, b, pa, pb, n);
+        float dist = o[11] + LINEAR_SLOP;
+        float pos_err = 0.f, vel_err = -rel;
+        if (dist > 0.f) vel_err -= dist / DT;
+        else pos_err = -dist * CONTACT_ERP / DT;
+        rn[34] = (pos_err + vel_err) * rn[33];
+        float t1[3], t2[3];
+        plane_space(n, t1, t2);
+        for (int f = 0; f < 2; f++) {
+            float* rf = L.rows[MAXC + 2 * c + f];
+            float relf = row_setup(L, rf, a, b, pa, pb, f == 0 ? t1 : t2);
+            rf[34] = -relf * rf[33];
+            rf[35] = L.con_mu[c];
+        }
+    }
+    wv::lds_sync();
+}
+
+/* this lane's slot in a row's Jacobian (or -1), and its response scale for block DoFs */
+__device__ __forceinline__ int lane_slot(int l, int ida, int idb, float& scale)
+{
+    scale = 0.f;
+    if (l < NJ) return l;
+    if (l < 16) return -1;
+    int b = (l - 16) >> 3, c = (l - 16) & 7;
+    if (c >= 6) return -1;
+    scale = c < 3 ? 1.f / BLOCK_MASS : 1.f / BLOCK_INERTIA;
+    if (b == ida) return 9 + c;
+    if (b == idb) return 15 + c;
+    return -1;
+}
+
+/* one Gauss-Seidel visit of LDS row `row`; dv is this lane's delta-velocity DoF.
+ * lo/hi are wave-uniform.  Returns the velocity change for the residual test. */
+__device__ __forceinline__ float contact_row_solve(float* row, float lo, float hi, float& dv)
+{
+    int l = wv::lane();
+    int ida = (int)row[37], idb = (int)row[38];
+    float scale;
+    int slot = lane_slot(l, ida, idb, scale);
+    float J = slot >= 0 ? row[slot] : 0.f;
+    float resp = l < NJ ? row[24 + l] : J * scale;
+    float jd = wv::sum_all(J * dv);
+    float dinv = row[33], app = row[36];
+    float delta = row[34] - jd * dinv;
+    float sum = app + delta;
+    if (sum < lo) { delta = lo - app; app = lo; }
+    else if (sum > hi) { delta = hi - app; app = hi; }
+    else app = sum;
+    row[36] = app; /* every lane stores the same value */
+    dv += resp * delta;
+    return dinv != 0.f ? delta / dinv : 0.f;
+}
+
+}  // namespace pmg
+#endif

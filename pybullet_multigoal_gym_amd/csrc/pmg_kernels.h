@@ -6,7 +6,7 @@
 #ifndef PMG_KERNELS_H
 #define PMG_KERNELS_H
 
-#include "pmg_device.h"
+#include "pmg_contact.h"
 
 namespace pmg {
 
@@ -154,12 +154,33 @@ __device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const
 }
 
 /* ------------------------------------------------------------------ */
-/* one 2 ms substep of the robot (no contacts in this path yet)         */
-__device__ __forceinline__ void robot_substep(const LaneConst& c, float& q, float& qd, float tau, float mtarget, float mimp)
+/* one 2 ms substep: collide, unconstrained velocities, PGS rows, integrate
+ * ([BULLET-PRIOR] btMultiBodyDynamicsWorld::internalSingleStepSimulation)  */
+template <int NB, int MAXC>
+__device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>& L, const LaneConst& c, float& q, float& qd,
+                                        float tau, float mtarget, float mimp)
 {
     int l = wv::lane();
+    const int nb = NB > 0 ? P.nb : 0;
     Kin k;
     fk(c, q, k);
+    /* publish what the contact lanes need: finger boxes, joint subspaces, block rotations */
+    if (l == 7 || l == 8) {
+        float* f = L.fing[l - 7];
+#pragma unroll
+        for (int a = 0; a < 3; a++) f[a] = k.p[a];
+#pragma unroll
+        for (int a = 0; a < 9; a++) f[3 + a] = k.R[a];
+    }
+    if (l < NJ) {
+#pragma unroll
+        for (int a = 0; a < 6; a++) L.S[l][a] = k.S[a];
+    }
+    if (l < nb) quat_to_R(L.blk[l] + 3, L.blkR[l]);
+    wv::lds_sync();
+    int nc = collide(L, nb, P.table_c, P.table_h, P.table_mu);
+
+    /* unconstrained velocity update: robot (CRBA + RNEA) ... */
     float I10[10], minv[NJ], v[6];
     body_inertia(c, k, I10);
     if (l >= NJ) {
@@ -173,22 +194,85 @@ __device__ __forceinline__ void robot_substep(const LaneConst& c, float& q, floa
 #pragma unroll
     for (int j = 0; j < NJ; j++) qdd += minv[j] * wv::bcast(rq, j);
     qd += DT * qdd;
+    /* ... and the free blocks: gravity + Bullet's base damping (isotropic inertia: no gyroscopic term) */
+    if (l < nb) {
+        float* b = L.blk[l];
+        float kl = LINK_DAMPING * (1.f + sqrtf(dot3(b + 7, b + 7))), ka = LINK_DAMPING * (1.f + sqrtf(dot3(b + 10, b + 10)));
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            b[7 + a] += DT * (-b[7 + a] * kl + (a == 2 ? -GRAVITY : 0.f));
+            b[10 + a] += DT * (-b[10 + a] * ka);
+        }
+    }
+    if (nc > 0) {
+        if (l < NJ) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) L.minv[l][j] = minv[j];
+            L.qd[l] = qd;
+        }
+        wv::lds_sync();
+        build_contact_rows(L, nc);
+    }
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
-    float dqd = 0.f;
+    float dv = 0.f; /* lanes 0..8: joint velocity change; lanes 16+8b+c: block b component c */
     for (int it = 0; it < SOLVER_ITERS; it++) {
         float resid = 0.f;
-        nc_sweep(r, (it & 1) != 0, minv, dqd, resid);
+        nc_sweep(r, (it & 1) != 0, minv, dv, resid);
+        for (int cc = 0; cc < nc; cc++) {
+            float d = contact_row_solve(L.rows[cc], 0.f, 1e10f, dv);
+            resid = fmaxf(resid, d * d);
+        }
+        for (int cc = 0; cc < 2 * nc; cc++) {
+            float* row = L.rows[MAXC + cc];
+            float tot = L.rows[cc >> 1][36];
+            if (tot > 0.f) {
+                float lim = row[35] * tot;
+                float d = contact_row_solve(row, -lim, lim, dv);
+                resid = fmaxf(resid, d * d);
+            }
+        }
         if (resid <= RESIDUAL_THRESHOLD) break;
     }
-    qd += dqd;
+    if (l < NJ) qd += dv;
     q += DT * qd;
+    if (NB > 0) {
+        if (l >= 16) {
+            int b = (l - 16) >> 3, cc = (l - 16) & 7;
+            if (b < nb && cc < 6) L.blk[b][7 + cc] += dv;
+        }
+        wv::lds_sync();
+        if (l < nb) {
+            float* b = L.blk[l];
+#pragma unroll
+            for (int a = 0; a < 3; a++) b[a] += DT * b[7 + a];
+            /* quat <- exp(omega dt) * quat */
+            float wn = sqrtf(dot3(b + 10, b + 10));
+            float ang = wn * DT;
+            float dq[4] = {0.f, 0.f, 0.f, 1.f};
+            if (ang > 1e-12f) {
+                float sh, ch;
+                sincosf(0.5f * ang, &sh, &ch);
+                float s = sh / wn;
+                dq[0] = b[10] * s; dq[1] = b[11] * s; dq[2] = b[12] * s; dq[3] = ch;
+            }
+            float x = dq[3] * b[3] + dq[0] * b[6] + dq[1] * b[5] - dq[2] * b[4];
+            float y = dq[3] * b[4] + dq[1] * b[6] + dq[2] * b[3] - dq[0] * b[5];
+            float z = dq[3] * b[5] + dq[2] * b[6] + dq[0] * b[4] - dq[1] * b[3];
+            float w = dq[3] * b[6] - dq[0] * b[3] - dq[1] * b[4] - dq[2] * b[5];
+            float inv = 1.f / sqrtf(x * x + y * y + z * z + w * w);
+            b[3] = x * inv; b[4] = y * inv; b[5] = z * inv; b[6] = w * inv;
+        }
+        wv::lds_sync();
+    }
 }
 
 /* ------------------------------------------------------------------ */
 /* env.step(): kuka.py:167-225 + _get_obs + _compute_reward + TimeLimit */
+template <int NB, int MAXC>
 __device__ __forceinline__ void step_env(const EnvParams& P, const float* actions)
 {
+    __shared__ ContactLds<NB, MAXC> L;
     int env = (int)blockIdx.x, l = wv::lane();
     if (env >= P.n_envs) return;
     LaneConst c;
@@ -197,6 +281,9 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
     int ll = l < NJ ? l : 0;
     float q = hot[ll], qd = hot[9 + ll];
     if (l >= NJ) { q = 0.f; qd = 0.f; }
+    const int nb = NB > 0 ? P.nb : 0;
+    float* gblk = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
+    for (int i = l; i < BLOCK_DIM * nb; i += 64) L.blk[i / BLOCK_DIM][i % BLOCK_DIM] = gblk[i];
     const float* act = actions + (size_t)env * P.adim;
     float grip = hot[28];
     int elapsed = (int)hot[29];
@@ -217,15 +304,18 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
         if (l < 7) mtarget = qik;
     }
     if (l < 7) mimp = ARM_FORCE * PHYSICS_DT; /* kuka.py:282-290 */
+    wv::lds_sync();
     for (int s = 0; s < SIM_STEPS; s++) {  /* kuka.py:223-225 */
         float tau = -c.jdamp * qd;         /* joint damping latched per stepSimulation */
-        for (int ss = 0; ss < SUBSTEPS; ss++) robot_substep(c, q, qd, tau, mtarget, mimp);
+        for (int ss = 0; ss < SUBSTEPS; ss++) substep<NB, MAXC>(P, L, c, q, qd, tau, mtarget, mimp);
     }
     elapsed++;
     if (l < NJ) { hot[l] = q; hot[9 + l] = qd; }
     if (l < 3) hot[18 + l] = l == 0 ? ee[0] : (l == 1 ? ee[1] : ee[2]);
     if (l < 7) hot[21 + l] = jt;
     if (l == 0) { hot[28] = grip; hot[29] = (float)elapsed; hot[30] = 1.f; }
+    for (int i = l; i < BLOCK_DIM * nb; i += 64) gblk[i] = L.blk[i / BLOCK_DIM][i % BLOCK_DIM];
+    wv::lds_sync();
     write_outputs(P, env, c, q, qd, elapsed, true);
 }
 

@@ -7,9 +7,11 @@
 #include "pmg_kernels.h"
 #include "pmg_launch.h"
 
+/* three LDS footprints: reach (no blocks), one object (push / pick_and_place), block_stack (<= 5 blocks) */
+template <int NB, int MAXC>
 __global__ void __launch_bounds__(64) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
 {
-    pmg::step_env(P, actions);
+    pmg::step_env<NB, MAXC>(P, actions);
 }
 
 __global__ void __launch_bounds__(64) pmg_k_reset(pmg::EnvParams P, const unsigned char* __restrict__ mask)
@@ -38,7 +40,9 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    hipLaunchKernelGGL(pmg_k_step, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    else if (P.nb == 1) hipLaunchKernelGGL((pmg_k_step<1, 24>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    else hipLaunchKernelGGL((pmg_k_step<5, 48>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     return hipGetLastError();
 }
 hipError_t pmg_launch_reset(const pmg::EnvParams& P, const unsigned char* d_mask, hipStream_t s)
