@@ -50,14 +50,20 @@ __device__ __forceinline__ int clip_poly(const float (*in)[2], int n, float (*ou
 }
 
 /* SAT over the 15 axes + face clipping / edge-edge; <= 4 points; n points from B to A */
+constexpr int BOX_WORK = 104; /* floats of LDS workspace per pair lane */
+/* W: per-lane LDS workspace for the dynamically indexed arrays (private "scratch" memory would cost
+ * an HBM-path round trip per access; LDS is ~10x closer) */
 __device__ inline int box_box(const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb,
-                              const float* hb, float margin, CPoint* out)
+                              const float* hb, float margin, CPoint* out, float* W)
 {
-    float A[3][3], B[3][3];
+    float (*A)[3] = (float (*)[3])(W + 0);
+    float (*B)[3] = (float (*)[3])(W + 9);
     for (int i = 0; i < 3; i++)
         for (int a = 0; a < 3; a++) { A[i][a] = Ra[3 * a + i]; B[i][a] = Rb[3 * a + i]; }
     float d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
-    float C[3][3], Q[3][3], dA[3], dB[3];
+    float (*C)[3] = (float (*)[3])(W + 18);
+    float (*Q)[3] = (float (*)[3])(W + 27);
+    float dA[3], dB[3];
     for (int i = 0; i < 3; i++) {
         dA[i] = dot3(d, A[i]);
         dB[i] = dot3(d, B[i]);
@@ -133,11 +139,14 @@ __device__ inline int box_box(const float* ca, const float* Ra, const float* ha,
     int iu = (ia + 1) % 3, iv = (ia + 2) % 3, ru = (ax + 1) % 3, rv = (ax + 2) % 3;
     float fc[3];
     for (int a = 0; a < 3; a++) fc[a] = ci[a] + isg * hi[ia] * Ri[ia][a];
-    float poly[8][2], tmp[8][2], vz[4];
-    const float SU[4] = {1.f, -1.f, -1.f, 1.f}, SV[4] = {1.f, 1.f, -1.f, -1.f};
+    float (*poly)[2] = (float (*)[2])(W + 36);
+    float (*tmp)[2] = (float (*)[2])(W + 52);
+    float vz[4];
+#pragma unroll
     for (int c = 0; c < 4; c++) {
         float rel[3];
-        for (int a = 0; a < 3; a++) rel[a] = fc[a] + SU[c] * hi[iu] * Ri[iu][a] + SV[c] * hi[iv] * Ri[iv][a] - cr[a];
+        const float su = (c == 0 || c == 3) ? 1.f : -1.f, sv = c < 2 ? 1.f : -1.f;
+        for (int a = 0; a < 3; a++) rel[a] = fc[a] + su * hi[iu] * Ri[iu][a] + sv * hi[iv] * Ri[iv][a] - cr[a];
         poly[c][0] = dot3(rel, Rr[ru]);
         poly[c][1] = dot3(rel, Rr[rv]);
         vz[c] = dot3(rel, nr);
@@ -153,7 +162,8 @@ __device__ inline int box_box(const float* ca, const float* Ra, const float* ha,
     n = clip_poly(tmp, n, poly, 0, -1.f, hr[ru]);
     n = clip_poly(poly, n, tmp, 1, 1.f, hr[rv]);
     n = clip_poly(tmp, n, poly, 1, -1.f, hr[rv]);
-    float pts[8][3], sep[8];
+    float (*pts)[3] = (float (*)[3])(W + 68);
+    float* sep = W + 92;
     int m = 0;
     for (int c = 0; c < n; c++) {
         float z = z0 + gu * poly[c][0] + gv * poly[c][1];
@@ -164,7 +174,8 @@ __device__ inline int box_box(const float* ca, const float* Ra, const float* ha,
         m++;
     }
     if (m == 0) return 0;
-    int sel[4], ns = 0;
+    int* sel = (int*)(W + 100);
+    int ns = 0;
     if (m <= 4) {
         for (int c = 0; c < m; c++) sel[ns++] = c;
     } else {
@@ -248,6 +259,7 @@ struct ContactLds {
     float qd[NJ];
     float minv[NJ][NJ];
     int pair_count[NPAIR];
+    float work[NPAIR][BOX_WORK];               /* box_box workspace per pair lane */
     float stage[NPAIR][4][10];                 /* pa pb n dist per staged point */
     float con[MAXC][12];                       /* a b pa3 pb3 n3 dist -> [0]=a [1]=b [2..4]pa [5..7]pb [8..10]n [11]dist */
     float con_mu[MAXC];
@@ -276,6 +288,13 @@ __device__ __forceinline__ void decode_pair(int i, int nb, int& a, int& b)
     b = r < nb ? r : BODY_STATIC;
 }
 
+/* lowest z of the oriented finger box (exact AABB extent): a separating-axis bound for finger x table */
+__device__ __forceinline__ float finger_zmin(const float* c, const float* R)
+{
+    const float fh[3] = PMG_FINGER_HALF;
+    return c[2] - (fabsf(R[6]) * fh[0] + fabsf(R[7]) * fh[1] + fabsf(R[8]) * fh[2]);
+}
+
 /* collision detection for every candidate pair of this env; fills L.con / L.ncon (uniform) */
 template <int NB, int MAXC>
 __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const float* table_c, const float* table_h, float table_mu)
@@ -296,7 +315,7 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
         bool cull = false;
         if (b == BODY_STATIC) {
             cb = tc; Rb = I3; hb = th;
-            if (a >= BODY_FINGER1) cull = !(ca[2] - FINGER_RADIUS < tc[2] + th[2] + CONTACT_MARGIN);
+            if (a >= BODY_FINGER1) cull = !(finger_zmin(ca, Ra) < tc[2] + th[2] + CONTACT_MARGIN);
         } else {
             cb = L.blk[b]; Rb = L.blkR[b]; hb = bh;
             float dd[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
@@ -306,7 +325,7 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
         int n = 0;
         if (!cull) {
             CPoint cp[4];
-            n = box_box(ca, Ra, ha, cb, Rb, hb, CONTACT_MARGIN, cp);
+            n = box_box(ca, Ra, ha, cb, Rb, hb, CONTACT_MARGIN, cp, L.work[i]);
             for (int c = 0; c < n; c++) {
                 float* o = L.stage[i][c];
                 for (int k = 0; k < 3; k++) { o[k] = cp[c].pa[k]; o[3 + k] = cp[c].pb[k]; o[6 + k] = cp[c].n[k]; }
@@ -441,7 +460,8 @@ __device__ __forceinline__ float contact_row_solve(float* row, float lo, float h
     int slot = lane_slot(l, ida, idb, scale);
     float J = slot >= 0 ? row[slot] : 0.f;
     float resp = l < NJ ? row[24 + l] : J * scale;
-    float jd = wv::sum_all(J * dv);
+    /* rows without block DoFs (finger x table) live entirely in lanes 0..8: one DPP butterfly */
+    float jd = (ida < 0 && idb < 0) ? wv::sum_row0(J * dv) : wv::sum_all(J * dv);
     float dinv = row[33], app = row[36];
     float delta = row[34] - jd * dinv;
     float sum = app + delta;

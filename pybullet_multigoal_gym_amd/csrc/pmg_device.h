@@ -77,36 +77,57 @@ __constant__ float C_SUBC[NJ][2][3] = PMG_MB_SUBM_COM;
 __constant__ int C_ROWDOF[NJ] = {2, 3, 0, 1, 4, 7, 8, 5, 6};
 
 /* ---------------------------------------------------------------- */
-struct LaneConst { /* per-lane (= per movable link) model constants */
-    float rf[9], xyz[3], ax[3];
-    int prismatic;
-    float mass, h[3], ilo[6], dsum[3], sm[2], sc[2][3];
-    float jlo, jhi, jdamp;
+/* per-lane (= per movable link) model constants, staged ONCE per kernel in LDS
+ * ([field][lane], conflict-free) and read on demand: keeps ~40 VGPRs free in
+ * the 100-substep loop. */
+constexpr int LC_RF = 0, LC_XYZ = 9, LC_AX = 12, LC_PRISM = 15, LC_MASS = 16, LC_H = 17, LC_ILO = 20, LC_DSUM = 26,
+              LC_SM = 29, LC_SC = 31, LC_JLO = 37, LC_JHI = 38, LC_JDAMP = 39, LC_N = 40;
+struct LaneTabStore { float t[LC_N][16]; };
+struct LaneConst {
+    const LaneTabStore* st;
+    int col; /* min(lane, 8) */
+    __device__ __forceinline__ float get(int f) const { return st->t[f][col]; }
+    __device__ __forceinline__ float rf(int i) const { return get(LC_RF + i); }
+    __device__ __forceinline__ float xyz(int i) const { return get(LC_XYZ + i); }
+    __device__ __forceinline__ float ax(int i) const { return get(LC_AX + i); }
+    __device__ __forceinline__ bool prismatic() const { return get(LC_PRISM) != 0.f; }
+    __device__ __forceinline__ float mass() const { return get(LC_MASS); }
+    __device__ __forceinline__ float h(int i) const { return get(LC_H + i); }
+    __device__ __forceinline__ float ilo(int i) const { return get(LC_ILO + i); }
+    __device__ __forceinline__ float dsum(int i) const { return get(LC_DSUM + i); }
+    __device__ __forceinline__ float sm(int i) const { return get(LC_SM + i); }
+    __device__ __forceinline__ float sc(int s, int i) const { return get(LC_SC + 3 * s + i); }
+    __device__ __forceinline__ float jlo() const { return get(LC_JLO); }
+    __device__ __forceinline__ float jhi() const { return get(LC_JHI); }
+    __device__ __forceinline__ float jdamp() const { return get(LC_JDAMP); }
 };
 
-__device__ __forceinline__ void load_lane_const(LaneConst& c)
+__device__ __forceinline__ void load_lane_const(LaneTabStore& st, LaneConst& c)
 {
-    int l = wv::lane() < NJ ? wv::lane() : NJ - 1;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-        for (int b = 0; b < 3; b++) c.rf[3 * a + b] = C_JROT[l][a][b];
-        c.xyz[a] = C_JXYZ[l][a];
-        c.ax[a] = C_JAXIS[l][a];
-        c.h[a] = C_H[l][a];
-        c.dsum[a] = C_DSUM[l][a];
-        c.sc[0][a] = C_SUBC[l][0][a];
-        c.sc[1][a] = C_SUBC[l][1][a];
+    int l = wv::lane();
+    if (l < 16) {
+        int m = l < NJ ? l : NJ - 1;
+        for (int a = 0; a < 3; a++) {
+            for (int b = 0; b < 3; b++) st.t[LC_RF + 3 * a + b][l] = C_JROT[m][a][b];
+            st.t[LC_XYZ + a][l] = C_JXYZ[m][a];
+            st.t[LC_AX + a][l] = C_JAXIS[m][a];
+            st.t[LC_H + a][l] = C_H[m][a];
+            st.t[LC_DSUM + a][l] = C_DSUM[m][a];
+            st.t[LC_SC + a][l] = C_SUBC[m][0][a];
+            st.t[LC_SC + 3 + a][l] = C_SUBC[m][1][a];
+        }
+        for (int a = 0; a < 6; a++) st.t[LC_ILO + a][l] = C_ILO[m][a];
+        st.t[LC_PRISM][l] = (float)C_JTYPE[m];
+        st.t[LC_MASS][l] = C_MASS[m];
+        st.t[LC_SM][l] = C_SUBM[m][0];
+        st.t[LC_SM + 1][l] = C_SUBM[m][1];
+        st.t[LC_JLO][l] = C_JLO[m];
+        st.t[LC_JHI][l] = C_JHI[m];
+        st.t[LC_JDAMP][l] = C_JDAMP[m];
     }
-#pragma unroll
-    for (int a = 0; a < 6; a++) c.ilo[a] = C_ILO[l][a];
-    c.prismatic = C_JTYPE[l];
-    c.mass = C_MASS[l];
-    c.sm[0] = C_SUBM[l][0];
-    c.sm[1] = C_SUBM[l][1];
-    c.jlo = C_JLO[l];
-    c.jhi = C_JHI[l];
-    c.jdamp = C_JDAMP[l];
+    wv::lds_sync();
+    c.st = &st;
+    c.col = l < NJ ? l : NJ - 1;
 }
 
 /* ---------------------------------------------------------------- */
@@ -204,6 +225,21 @@ struct Kin {
     float S[6];       /* joint motion subspace */
 };
 
+/* one level of the affine-map scan: (R, p) <- (R', p') o (R, p) with (R', p') from lane i-S */
+template <int S>
+__device__ __forceinline__ void fk_scan_level(float* R, float* p)
+{
+    float A[9], a3[3];
+#pragma unroll
+    for (int a = 0; a < 9; a++) A[a] = wv::row_shr<S>(R[a], (a % 4 == 0) ? 1.f : 0.f);
+#pragma unroll
+    for (int a = 0; a < 3; a++) a3[a] = wv::row_shr<S>(p[a], 0.f);
+    float t[3];
+    mat3v(A, p, t);
+    p[0] = a3[0] + t[0]; p[1] = a3[1] + t[1]; p[2] = a3[2] + t[2];
+    mat3m(A, R, R);
+}
+
 /* forward kinematics of the chain; lanes >= 9 end up holding link 7's frame (lane 6's) */
 __device__ __forceinline__ void fk(const LaneConst& c, float q, Kin& k)
 {
@@ -211,47 +247,72 @@ __device__ __forceinline__ void fk(const LaneConst& c, float q, Kin& k)
     float Lo[12]; /* local rotation (9) + offset (3) in the parent frame */
     float sq, cq;
     sincosf(q, &sq, &cq);
-    if (c.prismatic) {
+    float rf[9], ax[3];
+#pragma unroll
+    for (int a = 0; a < 9; a++) rf[a] = c.rf(a);
+#pragma unroll
+    for (int a = 0; a < 3; a++) ax[a] = c.ax(a);
+    const bool prism = c.prismatic();
+    if (prism) {
         float d[3];
-        mat3v(c.rf, c.ax, d);
+        mat3v(rf, ax, d);
 #pragma unroll
-        for (int a = 0; a < 9; a++) Lo[a] = c.rf[a];
+        for (int a = 0; a < 9; a++) Lo[a] = rf[a];
 #pragma unroll
-        for (int a = 0; a < 3; a++) Lo[9 + a] = c.xyz[a] + d[a] * q;
+        for (int a = 0; a < 3; a++) Lo[9 + a] = c.xyz(a) + d[a] * q;
     } else { /* revolute about local z: L = Rfix * Rz(q) */
 #pragma unroll
         for (int r = 0; r < 3; r++) {
-            Lo[3 * r] = c.rf[3 * r] * cq + c.rf[3 * r + 1] * sq;
-            Lo[3 * r + 1] = c.rf[3 * r + 1] * cq - c.rf[3 * r] * sq;
-            Lo[3 * r + 2] = c.rf[3 * r + 2];
-            Lo[9 + r] = c.xyz[r];
+            Lo[3 * r] = rf[3 * r] * cq + rf[3 * r + 1] * sq;
+            Lo[3 * r + 1] = rf[3 * r + 1] * cq - rf[3 * r] * sq;
+            Lo[3 * r + 2] = rf[3 * r + 2];
+            Lo[9 + r] = c.xyz(r);
         }
     }
-    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+    /* inclusive scan of the affine maps (L, o) along lanes 0..7 with DPP row shifts:
+     * T_i <- T_{i-s} o T_i for s = 1, 2, 4 (lanes without a source keep T_i: the
+     * DPP fill is the identity map).  Lane 7 (finger 1) is a leaf of link 7 and
+     * may take part; lane 8 (finger 2) hangs off lane 6 and is patched after.   */
+    float R[9], p[3];
 #pragma unroll
-    for (int j = 0; j < 7; j++) {
-        float Lj[12];
-        wv::bcastn<12>(Lo, j, Lj);
-        if (l >= j) {
-            float t[3];
-            mat3v(R, Lj + 9, t);
-            p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
-            mat3m(R, Lj, R);
-        }
+    for (int a = 0; a < 9; a++) R[a] = Lo[a];
+#pragma unroll
+    for (int a = 0; a < 3; a++) p[a] = Lo[9 + a];
+    float own[12];
+#pragma unroll
+    for (int a = 0; a < 12; a++) own[a] = Lo[a];
+    if (l == 8) { /* keep lane 8 out of the chain: identity */
+#pragma unroll
+        for (int a = 0; a < 9; a++) R[a] = (a % 4 == 0) ? 1.f : 0.f;
+        p[0] = p[1] = p[2] = 0.f;
     }
-    if (l == 7 || l == 8) {
-        float t[3];
-        mat3v(R, Lo + 9, t);
-        p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
-        mat3m(R, Lo, R);
+    fk_scan_level<1>(R, p);
+    fk_scan_level<2>(R, p);
+    fk_scan_level<4>(R, p);
+    {   /* lane 8 = T_6 o T_8local; lanes >= 9 = T_6 (tip-side consumers) */
+        float A[9], a3[3];
+#pragma unroll
+        for (int a = 0; a < 9; a++) A[a] = wv::bcast(R[a], 6);
+#pragma unroll
+        for (int a = 0; a < 3; a++) a3[a] = wv::bcast(p[a], 6);
+        if (l == 8) {
+            float t[3];
+            mat3v(A, own + 9, t);
+            p[0] = a3[0] + t[0]; p[1] = a3[1] + t[1]; p[2] = a3[2] + t[2];
+            mat3m(A, own, R);
+        } else if (l >= NJ) {
+#pragma unroll
+            for (int a = 0; a < 9; a++) R[a] = A[a];
+            p[0] = a3[0]; p[1] = a3[1]; p[2] = a3[2];
+        }
     }
 #pragma unroll
     for (int a = 0; a < 9; a++) k.R[a] = R[a];
 #pragma unroll
     for (int a = 0; a < 3; a++) k.p[a] = p[a];
     float aw[3];
-    mat3v(R, c.ax, aw);
-    if (c.prismatic) {
+    mat3v(R, ax, aw);
+    if (prism) {
         k.S[0] = k.S[1] = k.S[2] = 0.f;
         k.S[3] = aw[0]; k.S[4] = aw[1]; k.S[5] = aw[2];
     } else {
@@ -377,14 +438,14 @@ __device__ __forceinline__ float ik_solve(const LaneConst& c, float q, const flo
         for (int a = 0; a < 6; a++)
 #pragma unroll
             for (int b = a; b < 6; b++) {
-                float s = wv::sum_row0(col[a] * col[b]);
+                float s = wv::row_sum(col[a] * col[b]);
                 if (a == b) s += IK_DAMPING;
                 A[a][b] = s;
                 A[b][a] = s;
             }
         spd6_solve(A, e);
         float dq = l < 7 ? dot6(col, e) : 0.f;
-        float mx = wv::max_row0(fabsf(dq));
+        float mx = wv::row_max(fabsf(dq));
         if (mx > IK_MAX_STEP) dq *= IK_MAX_STEP / mx;
         q += dq;
     }
@@ -401,10 +462,12 @@ struct Dyn {
 /* world-frame 10-parameter inertia of this lane's merged body */
 __device__ __forceinline__ void body_inertia(const LaneConst& c, const Kin& k, float* I10)
 {
-    float hw[3];
-    mat3v(k.R, c.h, hw);
+    float hw[3], hl[3] = {c.h(0), c.h(1), c.h(2)}, il[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++) il[a] = c.ilo(a);
+    mat3v(k.R, hl, hw);
     const float* p = k.p;
-    float m = c.mass;
+    float m = c.mass();
     I10[0] = m;
     I10[1] = m * p[0] + hw[0]; I10[2] = m * p[1] + hw[1]; I10[3] = m * p[2] + hw[2];
     /* R Ilo R^T */
@@ -412,9 +475,9 @@ __device__ __forceinline__ void body_inertia(const LaneConst& c, const Kin& k, f
     float T[9];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-        T[3 * r] = R[3 * r] * c.ilo[0] + R[3 * r + 1] * c.ilo[1] + R[3 * r + 2] * c.ilo[2];
-        T[3 * r + 1] = R[3 * r] * c.ilo[1] + R[3 * r + 1] * c.ilo[3] + R[3 * r + 2] * c.ilo[4];
-        T[3 * r + 2] = R[3 * r] * c.ilo[2] + R[3 * r + 1] * c.ilo[4] + R[3 * r + 2] * c.ilo[5];
+        T[3 * r] = R[3 * r] * il[0] + R[3 * r + 1] * il[1] + R[3 * r + 2] * il[2];
+        T[3 * r + 1] = R[3 * r] * il[1] + R[3 * r + 1] * il[3] + R[3 * r + 2] * il[4];
+        T[3 * r + 2] = R[3 * r] * il[2] + R[3 * r + 1] * il[4] + R[3 * r + 2] * il[5];
     }
     float I[6];
     I[0] = T[0] * R[0] + T[1] * R[1] + T[2] * R[2];
@@ -482,7 +545,7 @@ __device__ __forceinline__ void mass_inverse(const Kin& k, const float* I10, flo
 }
 
 /* bias torque h_l = S_l . sum_{subtree} (I a_b + v x* I v - f_ext) with gravity and Bullet's link damping */
-__device__ __forceinline__ float bias_torque(const LaneConst& c, const Kin& k, const float* I10, float qd, float* v_out)
+__device__ __forceinline__ float bias_torque(const LaneConst& c, const Kin& k, const float* I10, float qd)
 {
     float s[6], v[6], cb[6], ab[6];
 #pragma unroll
@@ -506,9 +569,9 @@ __device__ __forceinline__ float bias_torque(const LaneConst& c, const Kin& k, c
     {
         float wl[3], dw[3];
         const float* R = k.R;
-        wl[0] = (R[0] * v[0] + R[3] * v[1] + R[6] * v[2]) * c.dsum[0];
-        wl[1] = (R[1] * v[0] + R[4] * v[1] + R[7] * v[2]) * c.dsum[1];
-        wl[2] = (R[2] * v[0] + R[5] * v[1] + R[8] * v[2]) * c.dsum[2];
+        wl[0] = (R[0] * v[0] + R[3] * v[1] + R[6] * v[2]) * c.dsum(0);
+        wl[1] = (R[1] * v[0] + R[4] * v[1] + R[7] * v[2]) * c.dsum(1);
+        wl[2] = (R[2] * v[0] + R[5] * v[1] + R[8] * v[2]) * c.dsum(2);
         mat3v(R, wl, dw);
         float ka = LINK_DAMPING * (1.f + sqrtf(dot3(v, v)));
         f[0] += dw[0] * ka; f[1] += dw[1] * ka; f[2] += dw[2] * ka;
@@ -516,12 +579,12 @@ __device__ __forceinline__ float bias_torque(const LaneConst& c, const Kin& k, c
     /* link damping, linear, per massive sub-body at its own COM */
 #pragma unroll
     for (int sb = 0; sb < 2; sb++) {
-        float cw[3], vc[3], fd[3], nd[3];
-        mat3v(k.R, c.sc[sb], cw);
+        float cw[3], vc[3], fd[3], nd[3], scl[3] = {c.sc(sb, 0), c.sc(sb, 1), c.sc(sb, 2)};
+        mat3v(k.R, scl, cw);
         cw[0] += k.p[0]; cw[1] += k.p[1]; cw[2] += k.p[2];
         cross3(v, cw, vc);
         vc[0] += v[3]; vc[1] += v[4]; vc[2] += v[5];
-        float kl = c.sm[sb] * LINK_DAMPING * (1.f + sqrtf(dot3(vc, vc)));
+        float kl = c.sm(sb) * LINK_DAMPING * (1.f + sqrtf(dot3(vc, vc)));
         fd[0] = vc[0] * kl; fd[1] = vc[1] * kl; fd[2] = vc[2] * kl;
         cross3(cw, fd, nd);
         f[0] += nd[0]; f[1] += nd[1]; f[2] += nd[2];
@@ -534,21 +597,23 @@ __device__ __forceinline__ float bias_torque(const LaneConst& c, const Kin& k, c
     float fc[6];
 #pragma unroll
     for (int a = 0; a < 6; a++) fc[a] = chain_suffix(f[a]);
-#pragma unroll
-    for (int a = 0; a < 6; a++) v_out[a] = v[a];
     return dot6(k.S, fc);
 }
 
 /* ---------------------------------------------------------------- */
-/* non-contact constraint rows (joint motors + joint limits), replicated in every lane */
+/* non-contact constraint rows (joint motors + joint limits).  Lane d owns the
+ * motor row and the (optional) limit row of DoF d: their right-hand sides,
+ * 1/diag, impulse bounds and accumulated impulses live in that lane's
+ * registers; a visit broadcasts only the resulting impulse change. */
 struct NcRows {
-    float dinv[NJ];      /* 1 / (M^-1)_dd */
-    float rhs_m[NJ];     /* motor rows */
-    float rhs_l[NJ];     /* limit rows */
-    float imp_m[NJ];     /* motor max impulse (0 = disabled) */
-    float app_m[NJ], app_l[NJ];
-    unsigned lim_active; /* bit d: limit row of dof d exists */
-    unsigned lim_upper;  /* bit d: it is the upper limit (Jacobian -1) */
+    float dinv, den;     /* 1 / (M^-1)_dd and (M^-1)_dd */
+    float rhs_m, rhs_l;  /* motor / limit right-hand sides */
+    float imp_m;         /* motor max impulse (0 = disabled) */
+    float app_m, app_l;  /* accumulated impulses */
+    float prev_m, prev_l;/* their values at the start of the current iteration (residual test) */
+    float sg_l;          /* limit Jacobian sign: +1 lower, -1 upper */
+    unsigned mot_active; /* wave-uniform bit masks over DoFs */
+    unsigned lim_active;
 };
 
 __device__ __forceinline__ void build_nc_rows(const LaneConst& c, const float* minv, float q, float qd, float mtarget,
@@ -558,71 +623,75 @@ __device__ __forceinline__ void build_nc_rows(const LaneConst& c, const float* m
     float den = minv[0];
 #pragma unroll
     for (int j = 1; j < NJ; j++) den = (l == j) ? minv[j] : den;
-    float dinv = den > SIMD_EPS ? 1.f / den : 0.f;
+    r.den = den > SIMD_EPS ? den : 0.f;
+    r.dinv = den > SIMD_EPS ? 1.f / den : 0.f;
     /* btMultiBodyJointMotor: target velocity kp*(q*-q)/dt + qd + kd*(0-qd) */
     float tv = ARM_KP * (mtarget - q) / DT + qd + ARM_KD * (0.f - qd);
-    float rm = (tv - qd) * dinv;
+    r.rhs_m = (tv - qd) * r.dinv;
+    r.imp_m = mimp;
     /* btMultiBodyJointLimitConstraint: active when (q-lo) <= 0 or (hi-q) <= 0 */
-    float plo = q - c.jlo, phi = c.jhi - q;
+    float plo = q - c.jlo(), phi = c.jhi() - q;
     bool alo = plo <= 0.f, ahi = !alo && phi <= 0.f;
     float pen = alo ? plo : phi;
-    float sg = alo ? 1.f : -1.f;
-    float rl = (-pen * JOINT_ERP / DT - sg * qd) * dinv;
+    r.sg_l = alo ? 1.f : -1.f;
+    r.rhs_l = (-pen * JOINT_ERP / DT - r.sg_l * qd) * r.dinv;
+    r.app_m = r.app_l = r.prev_m = r.prev_l = 0.f;
     bool valid = wv::lane() < NJ;
-    unsigned long long ma = wv::ballot(valid && (alo || ahi)), mu = wv::ballot(valid && ahi);
-    r.lim_active = (unsigned)ma & 0x1FFu;
-    r.lim_upper = (unsigned)mu & 0x1FFu;
-#pragma unroll
-    for (int d = 0; d < NJ; d++) {
-        float t[4] = {dinv, rm, rl, mimp}, o[4];
-        wv::bcastn<4>(t, d, o);
-        r.dinv[d] = o[0]; r.rhs_m[d] = o[1]; r.rhs_l[d] = o[2]; r.imp_m[d] = o[3];
-        r.app_m[d] = 0.f; r.app_l[d] = 0.f;
-    }
+    r.mot_active = (unsigned)wv::ballot(valid && mimp > 0.f) & 0x1FFu;
+    r.lim_active = (unsigned)wv::ballot(valid && (alo || ahi)) & 0x1FFu;
 }
 
-/* one Gauss-Seidel visit of a motor (kind 0) or limit (kind 1) row of dof D */
-template <int D>
-__device__ __forceinline__ void nc_row_solve(NcRows& r, int kind, const float* minv, float& dqd, float& resid)
+/* squared velocity change of the rows this lane owns during the iteration just finished
+ * (each row is visited once per iteration, so it is its impulse change times (M^-1)_dd) */
+__device__ __forceinline__ float nc_residual(NcRows& r)
 {
-    float dvd = wv::bcast(dqd, D);
-    float sg, rhs, lo, hi, app;
-    if (kind == 0) {
-        if (!(r.imp_m[D] > 0.f)) return;
-        sg = 1.f; rhs = r.rhs_m[D]; lo = -r.imp_m[D]; hi = r.imp_m[D]; app = r.app_m[D];
-    } else {
-        if (!((r.lim_active >> D) & 1u)) return;
-        sg = ((r.lim_upper >> D) & 1u) ? -1.f : 1.f; rhs = r.rhs_l[D]; lo = 0.f; hi = LIMIT_MAX_IMPULSE; app = r.app_l[D];
-    }
-    float delta = rhs - sg * dvd * r.dinv[D];
-    float sum = app + delta;
-    if (sum < lo) { delta = lo - app; app = lo; }
-    else if (sum > hi) { delta = hi - app; app = hi; }
-    else app = sum;
-    if (kind == 0) r.app_m[D] = app; else r.app_l[D] = app;
-    dqd += sg * minv[D] * delta;
-    float dv = r.dinv[D] != 0.f ? delta / r.dinv[D] : 0.f;
-    resid = fmaxf(resid, dv * dv);
+    float a = (r.app_m - r.prev_m) * r.den, b = (r.app_l - r.prev_l) * r.den;
+    r.prev_m = r.app_m;
+    r.prev_l = r.app_l;
+    return fmaxf(a * a, b * b);
+}
+
+/* one Gauss-Seidel visit of the motor (KIND 0) or limit (KIND 1) row of DoF D:
+ * every lane evaluates "its own" row in SIMD, lane D's impulse change is broadcast */
+template <int D, int KIND>
+__device__ __forceinline__ void nc_row_solve(NcRows& r, const float* minv, float& dqd)
+{
+    if (!(((KIND == 0 ? r.mot_active : r.lim_active) >> D) & 1u)) return;
+    float sg = KIND == 0 ? 1.f : r.sg_l;
+    float rhs = KIND == 0 ? r.rhs_m : r.rhs_l;
+    float lo = KIND == 0 ? -r.imp_m : 0.f, hi = KIND == 0 ? r.imp_m : LIMIT_MAX_IMPULSE;
+    float app = KIND == 0 ? r.app_m : r.app_l;
+    float sum = app + (rhs - sg * dqd * r.dinv);
+    float napp = __builtin_amdgcn_fmed3f(sum, lo, hi);
+    float sdelta = sg * (napp - app);          /* signed impulse change mapped to joint space */
+    float d = wv::bcast(sdelta, D);
+    bool mine = wv::lane() == D;
+    if (KIND == 0) r.app_m = mine ? napp : r.app_m; else r.app_l = mine ? napp : r.app_l;
+    dqd += minv[D] * d;
 }
 
 /* rows in list order: motors (dof 2,3,0,1,4,7,8,5,6) then limits (same dof order);
  * Bullet walks the list backwards on even iterations */
-__device__ __forceinline__ void nc_sweep(NcRows& r, bool forward, const float* minv, float& dqd, float& resid)
+__device__ __forceinline__ void nc_sweep(NcRows& r, bool forward, const float* minv, float& dqd)
 {
     if (forward) {
-        nc_row_solve<2>(r, 0, minv, dqd, resid); nc_row_solve<3>(r, 0, minv, dqd, resid); nc_row_solve<0>(r, 0, minv, dqd, resid);
-        nc_row_solve<1>(r, 0, minv, dqd, resid); nc_row_solve<4>(r, 0, minv, dqd, resid); nc_row_solve<7>(r, 0, minv, dqd, resid);
-        nc_row_solve<8>(r, 0, minv, dqd, resid); nc_row_solve<5>(r, 0, minv, dqd, resid); nc_row_solve<6>(r, 0, minv, dqd, resid);
-        nc_row_solve<2>(r, 1, minv, dqd, resid); nc_row_solve<3>(r, 1, minv, dqd, resid); nc_row_solve<0>(r, 1, minv, dqd, resid);
-        nc_row_solve<1>(r, 1, minv, dqd, resid); nc_row_solve<4>(r, 1, minv, dqd, resid); nc_row_solve<7>(r, 1, minv, dqd, resid);
-        nc_row_solve<8>(r, 1, minv, dqd, resid); nc_row_solve<5>(r, 1, minv, dqd, resid); nc_row_solve<6>(r, 1, minv, dqd, resid);
+        nc_row_solve<2, 0>(r, minv, dqd); nc_row_solve<3, 0>(r, minv, dqd); nc_row_solve<0, 0>(r, minv, dqd);
+        nc_row_solve<1, 0>(r, minv, dqd); nc_row_solve<4, 0>(r, minv, dqd); nc_row_solve<7, 0>(r, minv, dqd);
+        nc_row_solve<8, 0>(r, minv, dqd); nc_row_solve<5, 0>(r, minv, dqd); nc_row_solve<6, 0>(r, minv, dqd);
+        if (r.lim_active) {
+            nc_row_solve<2, 1>(r, minv, dqd); nc_row_solve<3, 1>(r, minv, dqd); nc_row_solve<0, 1>(r, minv, dqd);
+            nc_row_solve<1, 1>(r, minv, dqd); nc_row_solve<4, 1>(r, minv, dqd); nc_row_solve<7, 1>(r, minv, dqd);
+            nc_row_solve<8, 1>(r, minv, dqd); nc_row_solve<5, 1>(r, minv, dqd); nc_row_solve<6, 1>(r, minv, dqd);
+        }
     } else {
-        nc_row_solve<6>(r, 1, minv, dqd, resid); nc_row_solve<5>(r, 1, minv, dqd, resid); nc_row_solve<8>(r, 1, minv, dqd, resid);
-        nc_row_solve<7>(r, 1, minv, dqd, resid); nc_row_solve<4>(r, 1, minv, dqd, resid); nc_row_solve<1>(r, 1, minv, dqd, resid);
-        nc_row_solve<0>(r, 1, minv, dqd, resid); nc_row_solve<3>(r, 1, minv, dqd, resid); nc_row_solve<2>(r, 1, minv, dqd, resid);
-        nc_row_solve<6>(r, 0, minv, dqd, resid); nc_row_solve<5>(r, 0, minv, dqd, resid); nc_row_solve<8>(r, 0, minv, dqd, resid);
-        nc_row_solve<7>(r, 0, minv, dqd, resid); nc_row_solve<4>(r, 0, minv, dqd, resid); nc_row_solve<1>(r, 0, minv, dqd, resid);
-        nc_row_solve<0>(r, 0, minv, dqd, resid); nc_row_solve<3>(r, 0, minv, dqd, resid); nc_row_solve<2>(r, 0, minv, dqd, resid);
+        if (r.lim_active) {
+            nc_row_solve<6, 1>(r, minv, dqd); nc_row_solve<5, 1>(r, minv, dqd); nc_row_solve<8, 1>(r, minv, dqd);
+            nc_row_solve<7, 1>(r, minv, dqd); nc_row_solve<4, 1>(r, minv, dqd); nc_row_solve<1, 1>(r, minv, dqd);
+            nc_row_solve<0, 1>(r, minv, dqd); nc_row_solve<3, 1>(r, minv, dqd); nc_row_solve<2, 1>(r, minv, dqd);
+        }
+        nc_row_solve<6, 0>(r, minv, dqd); nc_row_solve<5, 0>(r, minv, dqd); nc_row_solve<8, 0>(r, minv, dqd);
+        nc_row_solve<7, 0>(r, minv, dqd); nc_row_solve<4, 0>(r, minv, dqd); nc_row_solve<1, 0>(r, minv, dqd);
+        nc_row_solve<0, 0>(r, minv, dqd); nc_row_solve<3, 0>(r, minv, dqd); nc_row_solve<2, 0>(r, minv, dqd);
     }
 }
 

@@ -154,17 +154,22 @@ __device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const
 }
 
 /* ------------------------------------------------------------------ */
-/* one 2 ms substep: collide, unconstrained velocities, PGS rows, integrate
- * ([BULLET-PRIOR] btMultiBodyDynamicsWorld::internalSingleStepSimulation)  */
+/* contact phases of a substep.  For the reach kernel (no free bodies) they
+ * are rare (fingers at the table clip plane only), so they are kept out of
+ * line there to keep the register budget of the 100-substep loop small. */
 template <int NB, int MAXC>
-__device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>& L, const LaneConst& c, float& q, float& qd,
-                                        float tau, float mtarget, float mimp)
+__device__ __noinline__ int collide_cold(ContactLds<NB, MAXC>& L, int nb, float tcx, float tcy, float tcz, float thx, float thy,
+                                         float thz, float tmu)
+{
+    float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
+    return collide(L, nb, tc, th, tmu);
+}
+/* publish (inline, from registers) what the pair / contact lanes need, then run the narrowphase */
+template <int NB, int MAXC>
+__device__ __forceinline__ int detect(ContactLds<NB, MAXC>& L, int nb, const Kin& k, float tcx, float tcy, float tcz, float thx,
+                                      float thy, float thz, float tmu)
 {
     int l = wv::lane();
-    const int nb = NB > 0 ? P.nb : 0;
-    Kin k;
-    fk(c, q, k);
-    /* publish what the contact lanes need: finger boxes, joint subspaces, block rotations */
     if (l == 7 || l == 8) {
         float* f = L.fing[l - 7];
 #pragma unroll
@@ -178,17 +183,58 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
     }
     if (l < nb) quat_to_R(L.blk[l] + 3, L.blkR[l]);
     wv::lds_sync();
-    int nc = collide(L, nb, P.table_c, P.table_h, P.table_mu);
+    if (NB == 0) return collide_cold<NB, MAXC>(L, nb, tcx, tcy, tcz, thx, thy, thz, tmu);
+    float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
+    return collide(L, nb, tc, th, tmu);
+}
+
+template <int NB, int MAXC>
+__device__ __noinline__ void build_rows_cold(ContactLds<NB, MAXC>& L, int nc)
+{
+    build_contact_rows(L, nc);
+}
+template <int NB, int MAXC>
+__device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const float* minv, float qd, int nc)
+{
+    int l = wv::lane();
+    if (l < NJ) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) L.minv[l][j] = minv[j];
+        L.qd[l] = qd;
+    }
+    wv::lds_sync();
+    if (NB == 0) build_rows_cold<NB, MAXC>(L, nc);
+    else build_contact_rows(L, nc);
+}
+
+/* ------------------------------------------------------------------ */
+/* one 2 ms substep: collide, unconstrained velocities, PGS rows, integrate
+ * ([BULLET-PRIOR] btMultiBodyDynamicsWorld::internalSingleStepSimulation)  */
+template <int NB, int MAXC>
+__device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>& L, const LaneConst& c_in, float& q, float& qd,
+                                        float tau, float mtarget, float mimp)
+{
+    int l = wv::lane();
+    const int nb = NB > 0 ? P.nb : 0;
+    LaneConst c = c_in;
+    wv::opaque(c.col); /* keep the LDS constant reads inside the loop (no 40-register hoist) */
+    Kin k;
+    fk(c, q, k);
+    /* contact detection; without free bodies it is skipped (wave-uniform) unless a finger is near the table */
+    int nc = 0;
+    bool low = (l == 7 || l == 8) && (finger_zmin(k.p, k.R) < P.table_c[2] + P.table_h[2] + CONTACT_MARGIN);
+    if (NB > 0 || wv::ballot(low) != 0ull)
+        nc = detect<NB, MAXC>(L, nb, k, P.table_c[0], P.table_c[1], P.table_c[2], P.table_h[0], P.table_h[1], P.table_h[2], P.table_mu);
 
     /* unconstrained velocity update: robot (CRBA + RNEA) ... */
-    float I10[10], minv[NJ], v[6];
+    float I10[10], minv[NJ];
     body_inertia(c, k, I10);
     if (l >= NJ) {
 #pragma unroll
         for (int a = 0; a < 10; a++) I10[a] = 0.f;
     }
+    float h = bias_torque(c, k, I10, qd);   /* bias first: its temporaries are dead before the matrix work */
     mass_inverse(k, I10, minv);
-    float h = bias_torque(c, k, I10, qd, v);
     float rq = l < NJ ? tau - h : 0.f;
     float qdd = 0.f;
 #pragma unroll
@@ -204,21 +250,13 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
             b[10 + a] += DT * (-b[10 + a] * ka);
         }
     }
-    if (nc > 0) {
-        if (l < NJ) {
-#pragma unroll
-            for (int j = 0; j < NJ; j++) L.minv[l][j] = minv[j];
-            L.qd[l] = qd;
-        }
-        wv::lds_sync();
-        build_contact_rows(L, nc);
-    }
+    if (nc > 0) prepare_rows<NB, MAXC>(L, minv, qd, nc);
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
     float dv = 0.f; /* lanes 0..8: joint velocity change; lanes 16+8b+c: block b component c */
     for (int it = 0; it < SOLVER_ITERS; it++) {
+        nc_sweep(r, (it & 1) != 0, minv, dv);
         float resid = 0.f;
-        nc_sweep(r, (it & 1) != 0, minv, dv, resid);
         for (int cc = 0; cc < nc; cc++) {
             float d = contact_row_solve(L.rows[cc], 0.f, 1e10f, dv);
             resid = fmaxf(resid, d * d);
@@ -232,6 +270,7 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
                 resid = fmaxf(resid, d * d);
             }
         }
+        resid = fmaxf(resid, wv::max_row0(nc_residual(r)));
         if (resid <= RESIDUAL_THRESHOLD) break;
     }
     if (l < NJ) qd += dv;
@@ -273,10 +312,11 @@ template <int NB, int MAXC>
 __device__ __forceinline__ void step_env(const EnvParams& P, const float* actions)
 {
     __shared__ ContactLds<NB, MAXC> L;
+    __shared__ LaneTabStore lcs;
     int env = (int)blockIdx.x, l = wv::lane();
     if (env >= P.n_envs) return;
     LaneConst c;
-    load_lane_const(c);
+    load_lane_const(lcs, c);
     float* hot = P.hot + (size_t)env * HOT_DIM;
     int ll = l < NJ ? l : 0;
     float q = hot[ll], qd = hot[9 + ll];
@@ -306,7 +346,7 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
     if (l < 7) mimp = ARM_FORCE * PHYSICS_DT; /* kuka.py:282-290 */
     wv::lds_sync();
     for (int s = 0; s < SIM_STEPS; s++) {  /* kuka.py:223-225 */
-        float tau = -c.jdamp * qd;         /* joint damping latched per stepSimulation */
+        float tau = -c.jdamp() * qd;         /* joint damping latched per stepSimulation */
         for (int ss = 0; ss < SUBSTEPS; ss++) substep<NB, MAXC>(P, L, c, q, qd, tau, mtarget, mimp);
     }
     elapsed++;
@@ -447,10 +487,11 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
 /* env.reset(): kuka.py:120-165 + the task reset above + _get_obs */
 __device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned char* mask)
 {
+    __shared__ LaneTabStore lcs;
     int env = (int)blockIdx.x, l = wv::lane();
     if (env >= P.n_envs) return;
     LaneConst c;
-    load_lane_const(c);
+    load_lane_const(lcs, c);
     float* hot = P.hot + (size_t)env * HOT_DIM;
     float* cold = P.cold + (size_t)env * COLD_DIM;
     int ll = l < NJ ? l : 0;

@@ -9,7 +9,7 @@
 
 /* three LDS footprints: reach (no blocks), one object (push / pick_and_place), block_stack (<= 5 blocks) */
 template <int NB, int MAXC>
-__global__ void __launch_bounds__(64) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(64, 4) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
 {
     pmg::step_env<NB, MAXC>(P, actions);
 }

@@ -81,6 +81,8 @@ __device__ __forceinline__ float max_all(float v)
     return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
 }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+/* optimisation barrier on a per-lane index: everything loaded through it is re-loaded */
+__device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
 
 }  // namespace wv
 #endif

@@ -34,6 +34,7 @@ extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__
 #define __shared__ static
 #define __restrict__
 #define __launch_bounds__(...)

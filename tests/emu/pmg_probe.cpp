@@ -10,8 +10,9 @@ extern "C" void pmge_probe_dynamics(const float* q, const float* qd, const float
     emu::launch(1, 64, [&]() {
         using namespace pmg;
         int l = wv::lane();
+        __shared__ LaneTabStore lcs;
         LaneConst c;
-        load_lane_const(c);
+        load_lane_const(lcs, c);
         float ql = l < NJ ? q[l] : 0.f, qdl = l < NJ ? qd[l] : 0.f, tl = l < NJ ? tau[l] : 0.f;
         Kin k;
         fk(c, ql, k);
@@ -22,7 +23,7 @@ extern "C" void pmge_probe_dynamics(const float* q, const float* qd, const float
         if (l >= NJ)
             for (int a = 0; a < 10; a++) I10[a] = 0.f;
         mass_inverse(k, I10, minv);
-        float h = bias_torque(c, k, I10, qdl, v);
+        float h = bias_torque(c, k, I10, qdl);
         float rq = l < NJ ? tl - h : 0.f;
         float acc = 0.f;
         for (int j = 0; j < NJ; j++) acc += minv[j] * wv::bcast(rq, j);
@@ -42,8 +43,9 @@ extern "C" int pmge_probe_ik(const float* q, const float* target, float* q_out)
     emu::launch(1, 64, [&]() {
         using namespace pmg;
         int l = wv::lane();
+        __shared__ LaneTabStore lcs;
         LaneConst c;
-        load_lane_const(c);
+        load_lane_const(lcs, c);
         float ql = l < NJ ? q[l] : 0.f;
         float r = ik_solve(c, ql, target);
         if (l < NJ) q_out[l] = r;

@@ -7,6 +7,7 @@
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 
 namespace wv {
 inline int lane() { return (int)threadIdx.x; }
@@ -93,6 +94,7 @@ inline float max_all(float v)
     v = row_max(v);
     return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
 }
+inline void opaque(int& i) { (void)i; }
 inline unsigned long long ballot(bool p)
 {
     float f = p ? 1.f : 0.f;
