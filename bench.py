@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--task', default='reach')
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--episode-steps', type=int, default=50)
     args = ap.parse_args()
 
     import torch
@@ -79,7 +80,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, 50
+    N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, args.episode_steps
     env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=local_rank, seed=0, seed_stride=1,
                        env_index_offset=rank * N, max_episode_steps=T)
     h = env.handle

@@ -1430,7 +1430,7 @@ static void task_reset_stack(const pmgo_env* e, World* w)
         }
     }
     for (int b = 0; b < e->nb; b++) set_block(&w->blk[b], (real)bp[b][0], (real)bp[b][1], (real)0.175);
-    for (int b = 0; b < e->nb; b++) w->order[b] = b;
+    for (int b = 0; b < NBMAX; b++) w->order[b] = b;
     if (e->cfg.random_order)
         for (int i = e->nb - 1; i >= 1; i--) {
             uint32_t j = mt_interval(&w->rng, (uint32_t)i);

@@ -29,7 +29,8 @@ constexpr int ROW_STRIDE = 40;                /* floats per constraint row in LD
 
 struct BoxPose { float c[3]; float R[9]; };
 
-struct CPoint { float pa[3], pb[3], n[3], dist; };
+/* a contact point record: pa[3] pb[3] n[3] dist (n from B to A), 10 floats, written straight into LDS */
+constexpr int CP = 10;
 
 __device__ __forceinline__ int clip_poly(const float (*in)[2], int n, float (*out)[2], int axis, float sign, float lim)
 {
@@ -54,7 +55,7 @@ constexpr int BOX_WORK = 104; /* floats of LDS workspace per pair lane */
 /* W: per-lane LDS workspace for the dynamically indexed arrays (private "scratch" memory would cost
  * an HBM-path round trip per access; LDS is ~10x closer) */
 __device__ inline int box_box(const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb,
-                              const float* hb, float margin, CPoint* out, float* W)
+                              const float* hb, float margin, float* out, float* W)
 {
     float (*A)[3] = (float (*)[3])(W + 0);
     float (*B)[3] = (float (*)[3])(W + 9);
@@ -115,11 +116,11 @@ __device__ inline int box_box(const float* ca, const float* Ra, const float* ha,
         float s = 0.f, t = 0.f;
         if (den > 1e-8f) { s = (q1 + uaub * q2) / den; t = (uaub * q1 + q2) / den; }
         for (int a = 0; a < 3; a++) {
-            out[0].pa[a] = pa[a] + s * A[i][a];
-            out[0].pb[a] = pb[a] + t * B[j][a];
-            out[0].n[a] = -nrm[a];
+            out[a] = pa[a] + s * A[i][a];
+            out[3 + a] = pb[a] + t * B[j][a];
+            out[6 + a] = -nrm[a];
         }
-        out[0].dist = best;
+        out[9] = best;
         return 1;
     }
     bool refA = code < 3;
@@ -208,10 +209,154 @@ __device__ inline int box_box(const float* ca, const float* Ra, const float* ha,
             pref[a] = base + hr[ax] * nr[a];
         }
         for (int a = 0; a < 3; a++) {
-            if (refA) { out[c].pa[a] = pref[a]; out[c].pb[a] = pin[a]; out[c].n[a] = -nr[a]; }
-            else { out[c].pa[a] = pin[a]; out[c].pb[a] = pref[a]; out[c].n[a] = nr[a]; }
+            if (refA) { out[CP * c + a] = pref[a]; out[CP * c + 3 + a] = pin[a]; out[CP * c + 6 + a] = -nr[a]; }
+            else { out[CP * c + a] = pin[a]; out[CP * c + 3 + a] = pref[a]; out[CP * c + 6 + a] = nr[a]; }
         }
-        out[c].dist = sep[s];
+        out[CP * c + 9] = sep[s];
+    }
+    return ns;
+}
+
+/* 3-way select with a dynamic index but register operands */
+__device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+/* Register-only front end of box_box: the 15-axis SAT with compile-time indices and the common
+ * face-contact case in which the incident face lies inside the reference face (block on table,
+ * finger over table, ...) so that no clipping is needed.  Same arithmetic, ordering and output as
+ * box_box(); everything else (edge-edge, partial overlap) falls through to the general routine. */
+__device__ inline int box_box_fast(const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb,
+                                   const float* hb, float margin, float* out, float* W)
+{
+    float A[3][3], B[3][3], HA[3], HB[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        HA[i] = ha[i]; HB[i] = hb[i];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { A[i][a] = Ra[3 * a + i]; B[i][a] = Rb[3 * a + i]; }
+    }
+    float d[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+    float C[3][3], Q[3][3], dA[3], dB[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        dA[i] = dot3(d, A[i]);
+        dB[i] = dot3(d, B[i]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) { C[i][j] = dot3(A[i], B[j]); Q[i][j] = fabsf(C[i][j]); }
+    }
+    float best = -1e30f;
+    int code = -1;
+    bool sep_axis = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float s = fabsf(dA[i]) - (HA[i] + HB[0] * Q[i][0] + HB[1] * Q[i][1] + HB[2] * Q[i][2]);
+        sep_axis = sep_axis || s > margin;
+        if (s > best) { best = s; code = i; }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        float s = fabsf(dB[j]) - (HB[j] + HA[0] * Q[0][j] + HA[1] * Q[1][j] + HA[2] * Q[2][j]);
+        sep_axis = sep_axis || s > margin;
+        if (s > best) { best = s; code = 3 + j; }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            float Lx[3];
+            cross3(A[i], B[j], Lx);
+            float len = sqrtf(dot3(Lx, Lx));
+            float proj = dot3(d, Lx);
+            float ra = HA[i1] * Q[i2][j] + HA[i2] * Q[i1][j];
+            float rb = HB[j1] * Q[i][j2] + HB[j2] * Q[i][j1];
+            bool valid = !(len < 1e-6f);
+            float s = (fabsf(proj) - (ra + rb)) / len;
+            sep_axis = sep_axis || (valid && s > margin);
+            float pen = s < 0.f ? s * EDGE_FUDGE : s / EDGE_FUDGE;
+            if (valid && pen > best) { best = s; code = 6 + 3 * i + j; }
+        }
+    if (sep_axis || code < 0) return 0;
+    if (code >= 6) return box_box(ca, Ra, ha, cb, Rb, hb, margin, out, W);
+    const bool refA = code < 3;
+    const int ax = refA ? code : code - 3;
+    /* reference / incident frames through selects (no dynamic register indexing) */
+    float Rr[3][3], Ri[3][3], hr[3], hi[3], cr[3], ci[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        hr[k] = refA ? HA[k] : HB[k]; hi[k] = refA ? HB[k] : HA[k];
+        cr[k] = refA ? ca[k] : cb[k]; ci[k] = refA ? cb[k] : ca[k];
+#pragma unroll
+        for (int a = 0; a < 3; a++) { Rr[k][a] = refA ? A[k][a] : B[k][a]; Ri[k][a] = refA ? B[k][a] : A[k][a]; }
+    }
+    float dax = sel3(ax, refA ? dA[0] : dB[0], refA ? dA[1] : dB[1], refA ? dA[2] : dB[2]);
+    float sgn = dax < 0.f ? -1.f : 1.f; /* axis direction from A towards B */
+    float rn[3], rU[3], rV[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        rn[a] = sel3(ax, Rr[0][a], Rr[1][a], Rr[2][a]);
+        rU[a] = sel3(ax, Rr[1][a], Rr[2][a], Rr[0][a]);
+        rV[a] = sel3(ax, Rr[2][a], Rr[0][a], Rr[1][a]);
+    }
+    float hrn = sel3(ax, hr[0], hr[1], hr[2]), hru = sel3(ax, hr[1], hr[2], hr[0]), hrv = sel3(ax, hr[2], hr[0], hr[1]);
+    /* nr: outward reference-face normal pointing at the incident box */
+    float nsg = refA ? sgn : -sgn;
+    float nr[3] = {nsg * rn[0], nsg * rn[1], nsg * rn[2]};
+    int ia = 0;
+    float bestd = -1.f;
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) {
+        float dd = fabsf(dot3(nr, Ri[kx]));
+        if (dd > bestd) { bestd = dd; ia = kx; }
+    }
+    float in_[3], iU[3], iV[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        in_[a] = sel3(ia, Ri[0][a], Ri[1][a], Ri[2][a]);
+        iU[a] = sel3(ia, Ri[1][a], Ri[2][a], Ri[0][a]);
+        iV[a] = sel3(ia, Ri[2][a], Ri[0][a], Ri[1][a]);
+    }
+    float hin = sel3(ia, hi[0], hi[1], hi[2]), hiu = sel3(ia, hi[1], hi[2], hi[0]), hiv = sel3(ia, hi[2], hi[0], hi[1]);
+    float isg = dot3(nr, in_) > 0.f ? -1.f : 1.f;
+    float fc[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) fc[a] = ci[a] + isg * hin * in_[a];
+    float pu[4], pv[4], vz[4];
+    bool inside = true;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const float su = (c == 0 || c == 3) ? 1.f : -1.f, sv = c < 2 ? 1.f : -1.f;
+        float rel[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) rel[a] = fc[a] + su * hiu * iU[a] + sv * hiv * iV[a] - cr[a];
+        pu[c] = dot3(rel, rU);
+        pv[c] = dot3(rel, rV);
+        vz[c] = dot3(rel, nr);
+        inside = inside && fabsf(pu[c]) <= hru && fabsf(pv[c]) <= hrv;
+    }
+    if (!inside) return box_box(ca, Ra, ha, cb, Rb, hb, margin, out, W);
+    float e1u = pu[1] - pu[0], e1v = pv[1] - pv[0], e1z = vz[1] - vz[0];
+    float e2u = pu[3] - pu[0], e2v = pv[3] - pv[0], e2z = vz[3] - vz[0];
+    float det = e1u * e2v - e1v * e2u;
+    float gu = 0.f, gv = 0.f;
+    if (fabsf(det) > 1e-12f) { gu = (e1z * e2v - e2z * e1v) / det; gv = (e2z * e1u - e1z * e2u) / det; }
+    float z0 = vz[0] - gu * pu[0] - gv * pv[0];
+    int ns = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        float z = z0 + gu * pu[c] + gv * pv[c];
+        float sp = z - hrn;
+        if (sp > margin) continue;
+        float* o = out + CP * ns;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            float base = cr[a] + pu[c] * rU[a] + pv[c] * rV[a];
+            float pin = base + z * nr[a], pref = base + hrn * nr[a];
+            o[a] = refA ? pref : pin;
+            o[3 + a] = refA ? pin : pref;
+            o[6 + a] = refA ? -nr[a] : nr[a];
+        }
+        o[9] = sp;
+        ns++;
     }
     return ns;
 }
@@ -323,15 +468,7 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
             cull = dot3(dd, dd) > lim * lim;
         }
         int n = 0;
-        if (!cull) {
-            CPoint cp[4];
-            n = box_box(ca, Ra, ha, cb, Rb, hb, CONTACT_MARGIN, cp, L.work[i]);
-            for (int c = 0; c < n; c++) {
-                float* o = L.stage[i][c];
-                for (int k = 0; k < 3; k++) { o[k] = cp[c].pa[k]; o[3 + k] = cp[c].pb[k]; o[6 + k] = cp[c].n[k]; }
-                o[9] = cp[c].dist;
-            }
-        }
+        if (!cull) n = box_box_fast(ca, Ra, ha, cb, Rb, hb, CONTACT_MARGIN, &L.stage[i][0][0], L.work[i]);
         L.pair_count[i] = n;
     }
     wv::lds_sync();
@@ -450,27 +587,56 @@ __device__ __forceinline__ int lane_slot(int l, int ida, int idb, float& scale)
     return -1;
 }
 
-/* one Gauss-Seidel visit of LDS row `row`; dv is this lane's delta-velocity DoF.
- * lo/hi are wave-uniform.  Returns the velocity change for the residual test. */
-__device__ __forceinline__ float contact_row_solve(float* row, float lo, float hi, float& dv)
+/* per-lane registers of the contact rows: lane c owns the scalars of contact c's normal row and
+ * of its two friction rows (right-hand side, 1/diag, accumulated impulse), so that a visit needs
+ * only v_readlane broadcasts plus the two per-lane LDS reads of J and M^-1 J^T -- and no LDS
+ * store, which lets the loads of the next visit issue early. */
+struct ConRegs {
+    float dinv[3], rhs[3], app[3]; /* [0] normal, [1..2] friction */
+    float mu;
+    int ida, idb;
+};
+
+template <int NB, int MAXC>
+__device__ __forceinline__ void load_con_regs(ContactLds<NB, MAXC>& L, int nc, ConRegs& r)
+{
+    int c = wv::lane();
+    bool ok = c < nc;
+    int cc = ok ? c : 0;
+    const float* rn = L.rows[cc];
+    r.dinv[0] = ok ? rn[33] : 0.f; r.rhs[0] = ok ? rn[34] : 0.f; r.app[0] = 0.f;
+    r.ida = ok ? (int)rn[37] : -1; r.idb = ok ? (int)rn[38] : -1;
+#pragma unroll
+    for (int f = 0; f < 2; f++) {
+        const float* rf = L.rows[MAXC + 2 * cc + f];
+        r.dinv[1 + f] = ok ? rf[33] : 0.f; r.rhs[1 + f] = ok ? rf[34] : 0.f; r.app[1 + f] = 0.f;
+    }
+    r.mu = ok ? L.rows[MAXC + 2 * cc][35] : 0.f;
+}
+
+/* one Gauss-Seidel visit of row K (0 normal, 1/2 friction) of contact c (wave-uniform);
+ * dv is this lane's delta-velocity DoF.  Returns the velocity change for the residual test. */
+template <int K>
+__device__ __forceinline__ float contact_row_solve(const float* row, int c, ConRegs& r, float& dv)
 {
     int l = wv::lane();
-    int ida = (int)row[37], idb = (int)row[38];
+    float pk[4] = {r.rhs[K], r.dinv[K], r.app[K], K == 0 ? 0.f : r.mu * r.app[0]}, o[4];
+    wv::bcastn<4>(pk, c, o);
+    int ida = wv::bcast_i(r.ida, c), idb = wv::bcast_i(r.idb, c);
+    float lo = K == 0 ? 0.f : -o[3], hi = K == 0 ? 1e10f : o[3];
+    if (K != 0 && !(o[3] > 0.f)) return 0.f; /* friction rows wait for a positive normal impulse */
     float scale;
     int slot = lane_slot(l, ida, idb, scale);
     float J = slot >= 0 ? row[slot] : 0.f;
     float resp = l < NJ ? row[24 + l] : J * scale;
     /* rows without block DoFs (finger x table) live entirely in lanes 0..8: one DPP butterfly */
     float jd = (ida < 0 && idb < 0) ? wv::sum_row0(J * dv) : wv::sum_all(J * dv);
-    float dinv = row[33], app = row[36];
-    float delta = row[34] - jd * dinv;
-    float sum = app + delta;
-    if (sum < lo) { delta = lo - app; app = lo; }
-    else if (sum > hi) { delta = hi - app; app = hi; }
-    else app = sum;
-    row[36] = app; /* every lane stores the same value */
+    float sum = o[2] + (o[0] - jd * o[1]);
+    float napp = __builtin_amdgcn_fmed3f(sum, lo, hi);
+    float delta = napp - o[2];
+    if (l == c) r.app[K] = napp;
     dv += resp * delta;
-    return dinv != 0.f ? delta / dinv : 0.f;
+    return delta * (o[1] != 0.f ? 1.f / o[1] : 0.f);
 }
 
 }  // namespace pmg

@@ -345,6 +345,17 @@ __device__ __forceinline__ void tip_frame(const Kin& k, float* tip, float* Rt)
 /* inverse kinematics: damped least squares on the 6 x 7 tip Jacobian,
  * dq = J^T (J J^T + 0.5 I)^-1 e  ( == (J^T J + 0.5 I)^-1 J^T e of BussIK's
  * CalcDeltaThetasDLS2), <= 40 iterations, stop on position residual.      */
+/* [BULLET-PRIOR] btMatrix3x3::getRotation; the three "largest diagonal" cases are written out
+ * with constant indices so that nothing is dynamically indexed (no scratch in the IK loop) */
+__device__ __forceinline__ void quat_case(const float* m, int i, int j, int k, float* q)
+{
+    float s = sqrtf(m[4 * i] - m[4 * j] - m[4 * k] + 1.f);
+    q[i] = 0.5f * s;
+    s = 0.5f / s;
+    q[3] = (m[3 * k + j] - m[3 * j + k]) * s;
+    q[j] = (m[3 * j + i] + m[3 * i + j]) * s;
+    q[k] = (m[3 * k + i] + m[3 * i + k]) * s;
+}
 __device__ __forceinline__ void quat_from_R(const float* m, float* q)
 {
     float tr = m[0] + m[4] + m[8];
@@ -353,17 +364,10 @@ __device__ __forceinline__ void quat_from_R(const float* m, float* q)
         q[3] = 0.5f * s;
         s = 0.5f / s;
         q[0] = (m[7] - m[5]) * s; q[1] = (m[2] - m[6]) * s; q[2] = (m[3] - m[1]) * s;
+    } else if (m[0] < m[4]) {
+        if (m[4] < m[8]) quat_case(m, 2, 0, 1, q); else quat_case(m, 1, 2, 0, q);
     } else {
-        int i = m[0] < m[4] ? (m[4] < m[8] ? 2 : 1) : (m[0] < m[8] ? 2 : 0);
-        int j = (i + 1) % 3, kk = (i + 2) % 3;
-        float s = sqrtf(m[4 * i] - m[4 * j] - m[4 * kk] + 1.f);
-        float t[4];
-        t[i] = 0.5f * s;
-        s = 0.5f / s;
-        t[3] = (m[3 * kk + j] - m[3 * j + kk]) * s;
-        t[j] = (m[3 * j + i] + m[3 * i + j]) * s;
-        t[kk] = (m[3 * kk + i] + m[3 * i + kk]) * s;
-        q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
+        if (m[0] < m[8]) quat_case(m, 2, 0, 1, q); else quat_case(m, 0, 1, 2, q);
     }
 }
 

@@ -8,7 +8,17 @@
 
 #include "pmg_contact.h"
 
+#ifndef PMG_COLD_CONTACTS
+#define PMG_COLD_CONTACTS 0 /* 1: keep the reach kernel's rare contact phases out of line */
+#endif
+
 namespace pmg {
+
+#ifdef PMG_PROFILE
+#define PMG_TICK(i) do { long long t_ = wall_clock64(); if (wv::lane() == 0 && blockIdx.x == 0) P.prof[i] += t_ - tprev; tprev = wall_clock64(); } while (0)
+#else
+#define PMG_TICK(i) do { } while (0)
+#endif
 
 struct EnvParams {
     int n_envs, task, nb, grasping, has_obj, joint_control, binary_reward, max_steps, in_air, random_order;
@@ -25,6 +35,9 @@ struct EnvParams {
     float* blocks;   /* [N, BLOCK_DIM * nb] */
     unsigned* rng;   /* [N, 625] MT19937 state + index */
     float* out;      /* [N, packed]: obs | policy | ag | dg | reward | goal_achieved | done */
+#ifdef PMG_PROFILE
+    long long* prof; /* per-phase wall_clock64 ticks of env 0 */
+#endif
 };
 
 /* ------------------------------------------------------------------ */
@@ -183,7 +196,7 @@ __device__ __forceinline__ int detect(ContactLds<NB, MAXC>& L, int nb, const Kin
     }
     if (l < nb) quat_to_R(L.blk[l] + 3, L.blkR[l]);
     wv::lds_sync();
-    if (NB == 0) return collide_cold<NB, MAXC>(L, nb, tcx, tcy, tcz, thx, thy, thz, tmu);
+    if (PMG_COLD_CONTACTS && NB == 0) return collide_cold<NB, MAXC>(L, nb, tcx, tcy, tcz, thx, thy, thz, tmu);
     float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
     return collide(L, nb, tc, th, tmu);
 }
@@ -203,7 +216,7 @@ __device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const floa
         L.qd[l] = qd;
     }
     wv::lds_sync();
-    if (NB == 0) build_rows_cold<NB, MAXC>(L, nc);
+    if (PMG_COLD_CONTACTS && NB == 0) build_rows_cold<NB, MAXC>(L, nc);
     else build_contact_rows(L, nc);
 }
 
@@ -216,16 +229,21 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
 {
     int l = wv::lane();
     const int nb = NB > 0 ? P.nb : 0;
+#ifdef PMG_PROFILE
+    long long tprev = wall_clock64();
+#endif
     LaneConst c = c_in;
     wv::opaque(c.col); /* keep the LDS constant reads inside the loop (no 40-register hoist) */
     Kin k;
     fk(c, q, k);
+    PMG_TICK(0);
     /* contact detection; without free bodies it is skipped (wave-uniform) unless a finger is near the table */
     int nc = 0;
     bool low = (l == 7 || l == 8) && (finger_zmin(k.p, k.R) < P.table_c[2] + P.table_h[2] + CONTACT_MARGIN);
     if (NB > 0 || wv::ballot(low) != 0ull)
         nc = detect<NB, MAXC>(L, nb, k, P.table_c[0], P.table_c[1], P.table_c[2], P.table_h[0], P.table_h[1], P.table_h[2], P.table_mu);
 
+    PMG_TICK(1);
     /* unconstrained velocity update: robot (CRBA + RNEA) ... */
     float I10[10], minv[NJ];
     body_inertia(c, k, I10);
@@ -250,7 +268,11 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
             b[10 + a] += DT * (-b[10 + a] * ka);
         }
     }
+    PMG_TICK(2);
     if (nc > 0) prepare_rows<NB, MAXC>(L, minv, qd, nc);
+    PMG_TICK(3);
+    ConRegs cr;
+    if (nc > 0) load_con_regs(L, nc, cr);
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
     float dv = 0.f; /* lanes 0..8: joint velocity change; lanes 16+8b+c: block b component c */
@@ -258,21 +280,18 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
         nc_sweep(r, (it & 1) != 0, minv, dv);
         float resid = 0.f;
         for (int cc = 0; cc < nc; cc++) {
-            float d = contact_row_solve(L.rows[cc], 0.f, 1e10f, dv);
+            float d = contact_row_solve<0>(L.rows[cc], cc, cr, dv);
             resid = fmaxf(resid, d * d);
         }
-        for (int cc = 0; cc < 2 * nc; cc++) {
-            float* row = L.rows[MAXC + cc];
-            float tot = L.rows[cc >> 1][36];
-            if (tot > 0.f) {
-                float lim = row[35] * tot;
-                float d = contact_row_solve(row, -lim, lim, dv);
-                resid = fmaxf(resid, d * d);
-            }
+        for (int cc = 0; cc < nc; cc++) {
+            float d1 = contact_row_solve<1>(L.rows[MAXC + 2 * cc], cc, cr, dv);
+            float d2 = contact_row_solve<2>(L.rows[MAXC + 2 * cc + 1], cc, cr, dv);
+            resid = fmaxf(resid, fmaxf(d1 * d1, d2 * d2));
         }
         resid = fmaxf(resid, wv::max_row0(nc_residual(r)));
         if (resid <= RESIDUAL_THRESHOLD) break;
     }
+    PMG_TICK(4);
     if (l < NJ) qd += dv;
     q += DT * qd;
     if (NB > 0) {
@@ -324,6 +343,9 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
     const int nb = NB > 0 ? P.nb : 0;
     float* gblk = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
     for (int i = l; i < BLOCK_DIM * nb; i += 64) L.blk[i / BLOCK_DIM][i % BLOCK_DIM] = gblk[i];
+#ifdef PMG_PROFILE
+    long long tprev = wall_clock64();
+#endif
     const float* act = actions + (size_t)env * P.adim;
     float grip = hot[28];
     int elapsed = (int)hot[29];
@@ -345,10 +367,12 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
     }
     if (l < 7) mimp = ARM_FORCE * PHYSICS_DT; /* kuka.py:282-290 */
     wv::lds_sync();
+    PMG_TICK(5);
     for (int s = 0; s < SIM_STEPS; s++) {  /* kuka.py:223-225 */
         float tau = -c.jdamp() * qd;         /* joint damping latched per stepSimulation */
         for (int ss = 0; ss < SUBSTEPS; ss++) substep<NB, MAXC>(P, L, c, q, qd, tau, mtarget, mimp);
     }
+    PMG_TICK(6);
     elapsed++;
     if (l < NJ) { hot[l] = q; hot[9 + l] = qd; }
     if (l < 3) hot[18 + l] = l == 0 ? ee[0] : (l == 1 ? ee[1] : ee[2]);
@@ -357,6 +381,7 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
     for (int i = l; i < BLOCK_DIM * nb; i += 64) gblk[i] = L.blk[i / BLOCK_DIM][i % BLOCK_DIM];
     wv::lds_sync();
     write_outputs(P, env, c, q, qd, elapsed, true);
+    PMG_TICK(7);
 }
 
 /* ------------------------------------------------------------------ */

@@ -1,0 +1,41 @@
+// debug harness: per-phase timing of the substep on env 0 (PMG_PROFILE build, not shipped)
+#define PMG_PROFILE 1
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstring>
+#include "pmg_kernels.h"
+template <int NB, int MAXC>
+__global__ void __launch_bounds__(64, 4) k_prof(pmg::EnvParams P, const float* act) { pmg::step_env<NB, MAXC>(P, act); }
+int main(int argc, char** argv)
+{
+    int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push
+    pmg::EnvParams P; memset(&P, 0, sizeof(P));
+    int N = argc > 3 ? atoi(argv[3]) : 4096; P.n_envs = N; P.task = task; P.nb = task == 0 ? 0 : 1; P.has_obj = task != 0; P.max_steps = 50; P.binary_reward = 1;
+    P.adim = 3; P.odim = task == 0 ? 3 : 20; P.pdim = task == 0 ? 3 : 7; P.gdim = 3; P.packed = P.odim + P.pdim + 9; P.thr = 0.05f;
+    float lo[3] = {-0.67f, -0.2f, 0.175f}, hi[3] = {-0.37f, 0.2f, 0.55f}, tc[3] = {-0.52f, 0, 0.08f}, th[3] = {0.25f, 0.35f, 0.08f};
+    for (int a = 0; a < 3; a++) { P.ee_lo[a] = lo[a]; P.ee_hi[a] = hi[a]; P.table_c[a] = tc[a]; P.table_h[a] = th[a]; }
+    P.table_mu = 0.1f;
+    std::vector<float> hot(N * 32, 0.f), goal(N * 16, 0.f), blk(N * 13, 0.f), act(N * 3, 0.f);
+    // joint pose with the tip at z ~ 0.176 (push start pose): from the oracle's reset
+    float q0[9] = {0.f, -0.4712f, 0.f, 1.9904f, 0.f, -0.6800f, 0.f, 0.035f, 0.035f};
+    float zt = argc > 2 ? atof(argv[2]) : 0.176f;
+    for (int i = 0; i < N; i++) { for (int d = 0; d < 9; d++) hot[i * 32 + d] = q0[d]; hot[i*32+18] = -0.52f; hot[i*32+19] = 0; hot[i*32+20] = zt; hot[i*32+28] = 0.035f;
+        blk[i*13+0] = -0.45f; blk[i*13+1] = 0.1f; blk[i*13+2] = 0.175f; blk[i*13+6] = 1.f; }
+    hipMalloc(&P.hot, hot.size()*4); hipMalloc(&P.cold, N*16*4); hipMalloc(&P.goal, goal.size()*4); hipMalloc(&P.blocks, blk.size()*4); hipMalloc(&P.out, (size_t)N*P.packed*4);
+    hipMalloc(&P.prof, 16*8); hipMemset(P.prof, 0, 16*8);
+    float* dact; hipMalloc(&dact, act.size()*4); hipMemcpy(dact, act.data(), act.size()*4, hipMemcpyHostToDevice);
+    hipMemcpy(P.hot, hot.data(), hot.size()*4, hipMemcpyHostToDevice); hipMemcpy(P.blocks, blk.data(), blk.size()*4, hipMemcpyHostToDevice); hipMemset(P.goal, 0, goal.size()*4);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int rep = 0; rep < 3; rep++) {
+        hipMemset(P.prof, 0, 16*8);
+        hipEventRecord(a);
+        if (task == 0) hipLaunchKernelGGL((k_prof<0, 8>), dim3(N), dim3(64), 0, 0, P, dact); else hipLaunchKernelGGL((k_prof<1, 24>), dim3(N), dim3(64), 0, 0, P, dact);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b);
+        long long pr[16]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
+        printf("task %d rep %d kernel %.3f ms | ticks/substep (100MHz): fk %.0f detect %.0f dyn %.0f rows %.0f pgs %.0f | whole-step ticks: ik %lld loop %lld out %lld\n", task, rep, ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5], pr[6], pr[7]);
+    }
+    std::vector<float> h2(N*32); hipMemcpy(h2.data(), P.hot, h2.size()*4, hipMemcpyDeviceToHost); printf("q0 after: %f %f %f ee z %f\n", h2[1], h2[3], h2[5], h2[20]);
+    return 0;
+}
