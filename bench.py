@@ -10,8 +10,11 @@ actions pre-generated and resident in HBM, episodes reset every
 max_episode_steps=50 steps inside the timed region, and -- for N > 1 -- one RCCL
 all-gather of the packed observation shard per step.  Rank 0 prints ONE JSON line.
 
-torch is used only for device buffers of the synthetic action table and for
-the torch.distributed rendezvous; the env itself is the C-ABI HIP library.
+The env is the C-ABI HIP library (ctypes); the synthetic action table is
+uploaded once into a device buffer it owns.  torch is imported only for the
+torch.distributed (gloo) rendezvous / barrier of multi-GPU runs -- it never
+creates a HIP context here (its wheel bundles a different HIP runtime than
+/opt/rocm).
 """
 import argparse
 import json
@@ -29,13 +32,25 @@ ALGO_BYTES = {'reach': 298, 'push': 486, 'pick_and_place': 490, 'block_stack': 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(task, budget_s=12.0):
     """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a
     bounded sample of the same workload: 64 envs per core, random actions, until
     ~budget_s of wall time has passed (at least 3 batched steps)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import oracle_lib
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n = 64 * cores
     ora = oracle_lib.OracleEnv(task, n, seed_base=0, seed_stride=1, threads=cores)
     ora.reset()
@@ -66,19 +81,18 @@ def main():
     ap.add_argument('--episode-steps', type=int, default=50)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     import pybullet_multigoal_gym_amd as pmg
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
     if world > 1:
+        import torch
+        import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('gloo')  # rendezvous + barrier only; the data path is RCCL inside the library
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
 
     N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, args.episode_steps
     env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=local_rank, seed=0, seed_stride=1,
@@ -90,24 +104,25 @@ def main():
         uid = [h.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         h.comm_init(rank, world, uid[0])
-        gathered = torch.empty((world * N, env.dims.packed_dim), dtype=torch.float32, device=dev)
-    # synthetic random policy: a table of K+W batches of U(-1,1) actions, resident in HBM
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(12345 + rank)
-    actions = torch.rand((K + W, N, A), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
-    torch.cuda.synchronize()
+        gathered = h.device_alloc(world * N * env.dims.packed_dim * 4)
+    # synthetic random policy: a table of K+W batches of U(-1,1) float32 actions, resident in HBM
+    table = np.random.RandomState(12345 + rank).uniform(-1, 1, (K + W, N, A)).astype(np.float32)
+    actions = h.device_alloc(table.nbytes)
+    h.upload(actions, table)
+    stride = N * A * 4
 
     def run(first, count):
         for t in range(first, first + count):
             if t % T == 0:
                 h.reset_device(None)
-            h.step_device(actions[t].data_ptr())
+            h.step_device(actions + t * stride)
             if gathered is not None:
-                h.allgather_packed(gathered.data_ptr())
+                h.allgather_packed(gathered)
 
     def fence():
-        h.sync()
-        torch.cuda.synchronize()
+        h.sync()                       # the library's stream: every kernel and the all-gather
+        if 'torch' in sys.modules and sys.modules['torch'].cuda.is_initialized():
+            sys.modules['torch'].cuda.synchronize()
         if world > 1:
             dist.barrier()
 
@@ -120,7 +135,7 @@ def main():
     el = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)   # slowest rank
         el = float(tt[0])
     kernel_ms, launches = h.timing_read()
 
@@ -147,6 +162,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.task)
         print(json.dumps(out), flush=True)
+    h.device_free(actions)
+    if gathered is not None:
+        h.device_free(gathered)
     env.close()
     if world > 1:
         dist.destroy_process_group()

@@ -48,17 +48,11 @@ enum {
     PMG_E_COMM = -5         /* RCCL error */
 };
 
-/* which output buffer pmg_device_ptr() returns */
+/* which device buffer pmg_device_ptr() returns */
 enum {
-    PMG_BUF_OBSERVATION = 0,
-    PMG_BUF_POLICY_STATE = 1,
-    PMG_BUF_ACHIEVED_GOAL = 2,
-    PMG_BUF_DESIRED_GOAL = 3,
-    PMG_BUF_REWARD = 4,
-    PMG_BUF_GOAL_ACHIEVED = 5,   /* uint8 */
-    PMG_BUF_DONE = 6,            /* uint8 */
-    PMG_BUF_PACKED = 7,          /* [N, packed_dim] float32: obs|policy|ag|dg|reward|goal_achieved|done */
-    PMG_BUF_STATE = 8            /* [N, state_dim] float32 persistent simulation state */
+    PMG_BUF_PACKED = 7,  /* [N, packed_dim] float32 rows: observation | policy_state | achieved_goal |
+                            desired_goal | reward | goal_achieved (0/1) | done (0/1); widths in pmg_dims */
+    PMG_BUF_STATE = 8    /* [N, 32] float32 hot state rows (q9 qd9 ee3 jt7 grip elapsed enabled resets) */
 };
 
 /* POD configuration; mirrors the kwargs of pmg.make_env (P/__init__.py:4-11)
@@ -154,6 +148,14 @@ int pmg_comm_unique_id(uint8_t id[128]);
 int pmg_comm_init(pmg_env* env, int rank, int nranks, const uint8_t id[128]);
 /* d_gathered: [nranks*N, packed_dim] device buffer (caller-owned). */
 int pmg_allgather_packed(pmg_env* env, float* d_gathered);
+
+/* Device-buffer helpers for callers that have no HIP runtime of their own (e.g. a numpy-only
+ * host): allocate / free / copy on the handle's device and stream.  Callers that already own
+ * device memory (a torch tensor's data_ptr()) pass those pointers directly instead. */
+int pmg_device_alloc(pmg_env* env, uint64_t bytes, void** d_ptr);
+int pmg_device_free(pmg_env* env, void* d_ptr);
+int pmg_upload(pmg_env* env, void* d_dst, const void* h_src, uint64_t bytes);   /* synchronous at return */
+int pmg_download(pmg_env* env, void* h_dst, const void* d_src, uint64_t bytes); /* synchronous at return */
 
 /* Kernel timing of the most recent *_device call sequence: HIP events on the
  * handle's stream bracket every step kernel; returns average ms per launch

@@ -44,7 +44,8 @@ class PmgLibrary:
     SYMBOLS = ['pmg_create', 'pmg_destroy', 'pmg_get_dims', 'pmg_last_error', 'pmg_seed', 'pmg_reset', 'pmg_step',
                'pmg_reset_device', 'pmg_step_device', 'pmg_device_ptr', 'pmg_stream', 'pmg_sync', 'pmg_read_outputs',
                'pmg_compute_reward', 'pmg_compute_reward_device', 'pmg_get_state', 'pmg_set_state', 'pmg_set_goal',
-               'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_read']
+               'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_read',
+               'pmg_device_alloc', 'pmg_device_free', 'pmg_upload', 'pmg_download']
 
     def __init__(self, path=None):
         self.path = path or DEFAULT_LIBRARY
@@ -190,6 +191,22 @@ class PmgHandle:
 
     def sync(self):
         self._check(self.L.lib.pmg_sync(self.h))
+
+    def device_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self.L.lib.pmg_device_alloc(self.h, C.c_uint64(nbytes), C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr):
+        self._check(self.L.lib.pmg_device_free(self.h, C.c_void_p(ptr)))
+
+    def upload(self, d_ptr, array):
+        a = np.ascontiguousarray(array)
+        self._check(self.L.lib.pmg_upload(self.h, C.c_void_p(d_ptr), _p(a), C.c_uint64(a.nbytes)))
+
+    def download(self, array, d_ptr):
+        assert array.flags['C_CONTIGUOUS']
+        self._check(self.L.lib.pmg_download(self.h, _p(array), C.c_void_p(d_ptr), C.c_uint64(array.nbytes)))
 
     def timing_reset(self):
         self._check(self.L.lib.pmg_timing_reset(self.h))

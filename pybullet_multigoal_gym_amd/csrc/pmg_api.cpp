@@ -543,6 +543,38 @@ int pmg_allgather_packed(pmg_env* e, float* d_gathered)
     return PMG_OK;
 }
 
+int pmg_device_alloc(pmg_env* e, uint64_t bytes, void** d_ptr)
+{
+    if (!e || !d_ptr) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (hipMalloc(d_ptr, bytes ? bytes : 1) != hipSuccess) return fail(e, PMG_E_NOMEM, "pmg_device_alloc: hipMalloc(%llu) failed", (unsigned long long)bytes);
+    return PMG_OK;
+}
+int pmg_device_free(pmg_env* e, void* d_ptr)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipFree(d_ptr));
+    return PMG_OK;
+}
+int pmg_upload(pmg_env* e, void* d_dst, const void* h_src, uint64_t bytes)
+{
+    if (!e || !d_dst || !h_src) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return PMG_OK;
+}
+int pmg_download(pmg_env* e, void* h_dst, const void* d_src, uint64_t bytes)
+{
+    if (!e || !h_dst || !d_src) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return PMG_OK;
+}
+
 int pmg_timing_reset(pmg_env* e)
 {
     if (!e) return PMG_E_INVALID;

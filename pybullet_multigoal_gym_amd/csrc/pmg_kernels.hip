@@ -7,9 +7,13 @@
 #include "pmg_kernels.h"
 #include "pmg_launch.h"
 
+#ifndef PMG_WAVES_PER_EU
+#define PMG_WAVES_PER_EU 2 /* the path is VALU-issue bound from 2 waves/SIMD on (profiles/r01): prefer 256 VGPRs and no spills */
+#endif
+
 /* three LDS footprints: reach (no blocks), one object (push / pick_and_place), block_stack (<= 5 blocks) */
 template <int NB, int MAXC>
-__global__ void __launch_bounds__(64, 4) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
 {
     pmg::step_env<NB, MAXC>(P, actions);
 }

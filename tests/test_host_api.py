@@ -1,0 +1,77 @@
+"""CPU tier: host logic of the product package (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pybullet_multigoal_gym_amd as pmg
+from pybullet_multigoal_gym_amd import spaces
+from pybullet_multigoal_gym_amd._lib import DEFAULT_LIBRARY, PmgConfig, PmgLibrary
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_library_loads_and_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(DEFAULT_LIBRARY)
+    hdr = open(os.path.join(ROOT, 'include', 'pmg.h')).read()
+    names = set(re.findall(r'\b(pmg_[a-z_]+)\s*\(', hdr))
+    assert len(names) >= 23
+    for n in sorted(names):
+        assert hasattr(lib, n), n
+    PmgLibrary()   # the typed binding agrees
+
+
+def test_config_struct_matches_header_size(built):
+    assert ctypes.sizeof(PmgConfig) == 88
+
+
+def test_product_refuses_to_run_without_a_gpu(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(Exception) as e:
+        pmg.make_env(task='reach', num_envs=2)
+    assert 'HIP' in str(e.value) or 'device' in str(e.value)
+
+
+def test_make_env_rejects_what_is_outside_the_hot_path(built):
+    with pytest.raises(ValueError):
+        pmg.make_env(task='fly')
+    with pytest.raises(AssertionError):
+        pmg.make_env(task='reach', gripper='claw')
+    for kw in [dict(task='chest_push'), dict(task='insertion'), dict(task='slide'), dict(gripper='robotiq85'),
+               dict(render=True), dict(image_observation=True), dict(goal_image=True), dict(task_decomposition=True),
+               dict(use_curriculum=True), dict(grip_informed_goal=True), dict(primitive='discrete_push')]:
+        with pytest.raises(NotImplementedError):
+            pmg.make_env(**kw)
+
+
+def test_spaces():
+    b = spaces.Box(-np.ones([4]), np.ones([4]))
+    assert b.shape == (4,) and b.contains(np.zeros(4, np.float32)) and not b.contains(np.full(4, 1.5))
+    assert b.sample().shape == (4,)
+    d = spaces.Dict({'a': b})
+    assert list(d.keys()) == ['a'] and d['a'] is b
+
+
+def test_env_wrapper_shapes_and_errors_on_the_emulator(emu_library):
+    """The Python host layer end to end, over the CPU emulator build of the same C ABI."""
+    env = pmg.make_env(task='reach', num_envs=None, _library=emu_library)
+    assert env.action_space.shape == (3,) and set(env.observation_space.keys()) >= {'observation', 'state', 'desired_goal'}
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(3, np.float32))            # gym TimeLimit: step before reset
+    o = env.reset()
+    assert o['observation'].shape == (3,) and o['observation'].dtype == np.float32
+    with pytest.raises(AssertionError):
+        env.step(np.float32([0, 0, 2]))              # outside Box(-1, 1), kuka.py:168
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(4, np.float32))
+    r, ok = env._compute_reward(np.float32([0, 0, 0]), np.float32([0, 0, 0.01]))
+    assert r.shape == () and r == 0 and bool(ok)
+    assert env.seed(5) == [5]
+    env.close()
+    env64 = pmg.make_env(task='reach', num_envs=2, dtype='float64', _library=emu_library)
+    assert env64.reset()['observation'].dtype == np.float64 and env64.reset()['observation'].shape == (2, 3)
+    env64.close()

@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json -- the vectors that CAN be pinned without PyBullet.
+
+Runs in the build container only.  Sources of truth:
+  * numpy's legacy RandomState (bit-stable MT19937 stream) seeded the way gym 0.17.3's
+    seeding.np_random does (sha512(str(seed))[:8] -> little-endian uint32 words);
+  * the reference's sampling rules, restated here in numpy with file:line citations
+    (P/ = /root/reference/pybullet_multigoal_gym/), so that the oracle's and the HIP
+    kernel's draws can be checked draw-by-draw:
+      P/robots/kuka.py:35-51                      workspace boxes
+      P/envs/base_envs/kuka_single_step_base_env.py:104-143   object + goal sampling
+      P/envs/base_envs/kuka_multi_step_base_env.py:221-235    block placement
+      P/envs/task_envs/kuka_multi_step_envs.py:34-74          stack order + base target
+  * the analytic FK known answer of SURVEY.md section 7-1.
+The reference package itself cannot be imported (gym / pybullet are absent).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+
+def gym_np_random(seed):
+    h = hashlib.sha512(str(seed).encode('utf8')).digest()[:8]
+    big = int.from_bytes(h, 'little')
+    ints = []
+    while big > 0:
+        big, mod = divmod(big, 2 ** 32)
+        ints.append(mod)
+    rs = np.random.RandomState()
+    rs.seed(ints or [0])
+    return rs, ints or [0]
+
+
+def boxes(task):
+    tip = np.array([-0.52, 0.0, 0.25])
+    if task == 'push':
+        tip[-1] = 0.175 + 0.001
+    lower = np.array([-0.67, -0.20, 0.175])
+    obj_lo, obj_hi = tip.copy() - 0.15, tip.copy() + 0.15
+    obj_lo[0] += 0.03; obj_hi[0] -= 0.03
+    tgt_lo, tgt_hi = tip.copy() - 0.15, tip.copy() + 0.15
+    tgt_lo[0] += 0.03; tgt_lo[-1] = lower[-1]; tgt_hi[0] -= 0.03
+    return tip, obj_lo, obj_hi, tgt_lo, tgt_hi
+
+
+def single_reset(rs, task):
+    tip, obj_lo, obj_hi, tgt_lo, tgt_hi = boxes(task)
+    has_obj, grasping, in_air = task != 'reach', task == 'pick_and_place', task in ('reach', 'pick_and_place')
+    obj = None
+    center = tip.copy()
+    if has_obj:
+        xy = tip[:2]
+        while np.linalg.norm(xy - tip[:2]) < 0.1:
+            xy = rs.uniform(obj_lo[:-1], obj_hi[:-1])
+        obj = np.append(xy, 0.175)
+        center = obj
+    while True:
+        g = rs.uniform(tgt_lo, tgt_hi)
+        if np.linalg.norm(g - center) > 0.1:
+            break
+    if not in_air:
+        g[2] = 0.175
+    elif grasping:
+        if rs.uniform(0, 1) >= 0.5:
+            g[2] = 0.175
+    return obj, g
+
+
+def stack_reset(rs, nb):
+    tip, obj_lo, obj_hi, tgt_lo, tgt_hi = boxes('block_stack')
+    poses = []
+    for _ in range(nb):
+        while True:
+            xy = rs.uniform(obj_lo[:-1], obj_hi[:-1])
+            if all(np.linalg.norm(xy - p[:-1]) > 0.06 for p in poses + [tip]):
+                poses.append(np.concatenate((xy, [0.175])))
+                break
+    order = np.arange(nb, dtype=int)
+    rs.shuffle(order)
+    while True:
+        b = rs.uniform(tgt_lo[:-1], tgt_hi[:-1])
+        if all(np.linalg.norm(b - p[:-1]) > 0.08 for p in poses):
+            break
+    goal = [None] * nb
+    for k in range(nb):
+        goal[order[k]] = [b[0], b[1], 0.175 + 0.03 * k]
+    return poses, order.tolist(), b.tolist(), np.concatenate(goal)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rng = {}
+    for seed in [0, 1, 2, 7, 12345, 2 ** 32 + 5, 2 ** 63 - 1]:
+        rs, ints = gym_np_random(seed)
+        d = rs.random_sample(64).tolist()
+        perm = np.arange(5)
+        rs.shuffle(perm)
+        rng[str(seed)] = {'init_key': ints, 'random_sample_64': d, 'then_shuffle_arange5': perm.tolist()}
+    json.dump(rng, open(os.path.join(OUT, 'rng.json'), 'w'), indent=0)
+
+    samp = {}
+    for task in ['reach', 'push', 'pick_and_place']:
+        for seed in [0, 3]:
+            rs, _ = gym_np_random(seed)
+            eps = []
+            for ep in range(6):  # episode 0 is the reset consumed by the reference's constructor (base_env.py:84)
+                obj, g = single_reset(rs, task)
+                eps.append({'object': None if obj is None else obj.tolist(), 'goal': g.tolist()})
+            samp['%s/%d' % (task, seed)] = eps
+    for nb in [2, 4, 5]:
+        for seed in [0, 3]:
+            rs, _ = gym_np_random(seed)
+            eps = []
+            for ep in range(4):
+                poses, order, base, goal = stack_reset(rs, nb)
+                eps.append({'blocks': [p.tolist() for p in poses], 'order': order, 'base': base, 'goal': goal.tolist()})
+            samp['block_stack%d/%d' % (nb, seed)] = eps
+    json.dump(samp, open(os.path.join(OUT, 'sampling.json'), 'w'), indent=0)
+
+    fk = {'rest_pose': [0, -0.5592432, 0, 1.733180, 0, -0.8501557, 0, 0.035, 0.035],
+          'tip_position': [-0.522923, 0.0, 0.250773], 'tip_position_tol': 1e-5,
+          'tip_rotation': [[-1, 0, 0], [0, 1, 0], [0, 0, -1]], 'tip_rotation_tol': 1.1e-3,
+          'source': 'SURVEY.md section 7-1 (computed independently in the survey session)'}
+    json.dump(fk, open(os.path.join(OUT, 'fk.json'), 'w'), indent=0)
+    print('wrote', sorted(os.listdir(OUT)))
+
+
+if __name__ == '__main__':
+    main()
