@@ -496,78 +496,111 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
     return total;
 }
 
-/* Jacobian entries of one contact direction; writes one LDS row and returns rel. velocity */
+/* LDS row of (contact c, direction t): t = 0 normal, 1..2 friction */
 template <int NB, int MAXC>
-__device__ __forceinline__ float row_setup(ContactLds<NB, MAXC>& L, float* row, int a, int b, const float* pa, const float* pb,
-                                           const float* dir)
+__device__ __forceinline__ float* row_of(ContactLds<NB, MAXC>& L, int c, int t)
 {
-    for (int k = 0; k < ROW_STRIDE; k++) row[k] = 0.f;
-    row[37] = -1.f; row[38] = -1.f;
-    float denom = 0.f, rel = 0.f;
-    bool has_robot = false;
-    for (int s = 0; s < 2; s++) {
-        float sg = s == 0 ? 1.f : -1.f;
-        int id = s == 0 ? a : b;
-        const float* pt = s == 0 ? pa : pb;
-        if (id == BODY_STATIC) continue;
-        if (id >= BODY_FINGER1) {
-            int own = id == BODY_FINGER1 ? 7 : 8;
-            for (int d = 0; d < NJ; d++) {
-                if (d >= 7 && d != own) continue;
-                const float* S = L.S[d];
-                float v[3];
-                cross3(S, pt, v);
-                v[0] += S[3]; v[1] += S[4]; v[2] += S[5];
-                row[d] += sg * dot3(v, dir);
-            }
-            has_robot = true;
-        } else {
-            const float* bl = L.blk[id];
-            float r[3] = {pt[0] - bl[0], pt[1] - bl[1], pt[2] - bl[2]}, rxn[3];
-            cross3(r, dir, rxn);
-            float* J = row + 9 + 6 * s;
-            for (int k = 0; k < 3; k++) { J[k] = sg * dir[k]; J[3 + k] = sg * rxn[k]; }
-            row[37 + s] = (float)id;
-            denom += dot3(J, J) / BLOCK_MASS + dot3(J + 3, J + 3) / BLOCK_INERTIA;
-            rel += dot3(J, bl + 7) + dot3(J + 3, bl + 10);
-        }
-    }
-    if (has_robot) {
-        for (int i = 0; i < NJ; i++) {
-            float s = 0.f;
-            for (int j = 0; j < NJ; j++) s += L.minv[i][j] * row[j];
-            row[24 + i] = s;
-        }
-        for (int d = 0; d < NJ; d++) { denom += row[d] * row[24 + d]; rel += row[d] * L.qd[d]; }
-        row[39] = 1.f;
-    }
-    row[33] = denom > SIMD_EPS ? 1.f / denom : 0.f;
-    return rel;
+    return t == 0 ? L.rows[c] : L.rows[MAXC + 2 * c + (t - 1)];
 }
 
-/* build the normal + 2 friction rows of every contact (lane = contact) */
+/* Build the normal + 2 friction rows of every contact in four lane-parallel phases:
+ *   R1 lane = contact:            friction directions, block-side Jacobians / 1/mass terms / velocities
+ *   R2 lane = (row, DoF) item:    robot Jacobian entries J[r][d] = (w_d x p + v_d) . dir
+ *   R3 lane = (row, DoF) item:    (M^-1 J^T)[r][i] = sum_j M^-1[i][j] J[r][j]
+ *   R4 lane = contact:            1/diag, relative velocity, right-hand sides
+ * ([BULLET-PRIOR] btMultiBodyConstraintSolver::setupMultiBodyContactConstraint) */
 template <int NB, int MAXC>
 __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int nc)
 {
     int l = wv::lane();
+    /* R1 */
     for (int c = l; c < nc; c += 64) {
         const float* o = L.con[c];
         int a = (int)o[0], b = (int)o[1];
-        float pa[3] = {o[2], o[3], o[4]}, pb[3] = {o[5], o[6], o[7]}, n[3] = {o[8], o[9], o[10]};
-        float* rn = L.rows[c];
-        float rel = row_setup(L, rn, a, b, pa, pb, n);
-        float dist = o[11] + LINEAR_SLOP;
-        float pos_err = 0.f, vel_err = -rel;
-        if (dist > 0.f) vel_err -= dist / DT;
-        else pos_err = -dist * CONTACT_ERP / DT;
-        rn[34] = (pos_err + vel_err) * rn[33];
-        float t1[3], t2[3];
+        float n[3] = {o[8], o[9], o[10]}, t1[3], t2[3];
         plane_space(n, t1, t2);
-        for (int f = 0; f < 2; f++) {
-            float* rf = L.rows[MAXC + 2 * c + f];
-            float relf = row_setup(L, rf, a, b, pa, pb, f == 0 ? t1 : t2);
-            rf[34] = -relf * rf[33];
-            rf[35] = L.con_mu[c];
+        for (int t = 0; t < 3; t++) {
+            float* row = row_of(L, c, t);
+            const float* dir = t == 0 ? n : (t == 1 ? t1 : t2);
+            for (int k = 0; k < ROW_STRIDE; k++) row[k] = 0.f;
+            row[21] = dir[0]; row[22] = dir[1]; row[23] = dir[2]; /* pad slots carry the direction to R2 */
+            float denom = 0.f, rel = 0.f;
+            row[37] = -1.f; row[38] = -1.f;
+            for (int s2 = 0; s2 < 2; s2++) {
+                int id = s2 == 0 ? a : b;
+                if (id < 0 || id >= BODY_FINGER1) continue;
+                float sg = s2 == 0 ? 1.f : -1.f;
+                const float* pt = o + 2 + 3 * s2;
+                const float* bl = L.blk[id];
+                float r[3] = {pt[0] - bl[0], pt[1] - bl[1], pt[2] - bl[2]}, rxn[3];
+                cross3(r, dir, rxn);
+                float* J = row + 9 + 6 * s2;
+                for (int k = 0; k < 3; k++) { J[k] = sg * dir[k]; J[3 + k] = sg * rxn[k]; }
+                row[37 + s2] = (float)id;
+                denom += dot3(J, J) / BLOCK_MASS + dot3(J + 3, J + 3) / BLOCK_INERTIA;
+                rel += dot3(J, bl + 7) + dot3(J + 3, bl + 10);
+            }
+            row[33] = denom;
+            row[34] = rel;
+            row[39] = (a >= BODY_FINGER1 || b >= BODY_FINGER1) ? 1.f : 0.f;
+        }
+    }
+    wv::lds_sync();
+    /* R2 */
+    for (int item = l; item < 27 * nc; item += 64) {
+        int c = item / 27, t = (item / 9) % 3, d = item % 9;
+        const float* o = L.con[c];
+        float* row = row_of(L, c, t);
+        float acc = 0.f;
+        for (int s2 = 0; s2 < 2; s2++) {
+            int id = (int)o[s2];
+            if (id < BODY_FINGER1) continue;
+            int own = id == BODY_FINGER1 ? 7 : 8;
+            if (d >= 7 && d != own) continue;
+            const float* S = L.S[d];
+            const float* pt = o + 2 + 3 * s2;
+            float v[3];
+            cross3(S, pt, v);
+            v[0] += S[3]; v[1] += S[4]; v[2] += S[5];
+            acc += (s2 == 0 ? 1.f : -1.f) * (v[0] * row[21] + v[1] * row[22] + v[2] * row[23]);
+        }
+        row[d] = acc;
+    }
+    wv::lds_sync();
+    /* R3 */
+    for (int item = l; item < 27 * nc; item += 64) {
+        int c = item / 27, t = (item / 9) % 3, i = item % 9;
+        float* row = row_of(L, c, t);
+        if (row[39] != 0.f) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) s += L.minv[i][j] * row[j];
+            row[24 + i] = s;
+        }
+    }
+    wv::lds_sync();
+    /* R4 */
+    for (int c = l; c < nc; c += 64) {
+        float dist = L.con[c][11] + LINEAR_SLOP;
+        for (int t = 0; t < 3; t++) {
+            float* row = row_of(L, c, t);
+            float denom = row[33], rel = row[34];
+            if (row[39] != 0.f) {
+#pragma unroll
+                for (int d = 0; d < NJ; d++) { denom += row[d] * row[24 + d]; rel += row[d] * L.qd[d]; }
+            }
+            float dinv = denom > SIMD_EPS ? 1.f / denom : 0.f;
+            row[33] = dinv;
+            if (t == 0) {
+                float pos_err = 0.f, vel_err = -rel;
+                if (dist > 0.f) vel_err -= dist / DT;
+                else pos_err = -dist * CONTACT_ERP / DT;
+                row[34] = (pos_err + vel_err) * dinv;
+            } else {
+                row[34] = -rel * dinv;
+                row[35] = L.con_mu[c];
+            }
+            row[21] = row[22] = row[23] = 0.f;
         }
     }
     wv::lds_sync();
@@ -637,6 +670,78 @@ __device__ __forceinline__ float contact_row_solve(const float* row, int c, ConR
     if (l == c) r.app[K] = napp;
     dv += resp * delta;
     return delta * (o[1] != 0.f ? 1.f / o[1] : 0.f);
+}
+
+/* ---------------------------------------------------------------- */
+/* Reach kernel (no free bodies): every contact row is finger x table and involves only the
+ * 9 robot DoFs in lanes 0..8.  With at most 8 contacts (2 fingers x 4 points) the whole row set
+ * fits in registers: lane k keeps J[r][k] and (M^-1 J^T)[r][k] of all 24 rows, the row scalars are
+ * replicated in every lane, and a visit is one multiply, one DPP butterfly and one fused update
+ * -- no LDS traffic and no scalar broadcasts inside the five solver iterations.             */
+template <int MAXC>
+struct RobotRows {
+    float J[3 * MAXC], R[3 * MAXC];          /* per lane (DoF) */
+    float rhs[3 * MAXC], dinv[3 * MAXC], app[3 * MAXC], mu[MAXC]; /* replicated */
+};
+
+template <int NB, int MAXC>
+__device__ __forceinline__ void load_robot_rows(ContactLds<NB, MAXC>& L, int nc, RobotRows<MAXC>& rr)
+{
+    int l = wv::lane();
+    int k = l < NJ ? l : 0;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const float* row = t == 0 ? L.rows[c] : L.rows[MAXC + 2 * c + (t - 1)];
+            bool ok = c < nc;
+            rr.J[3 * c + t] = (ok && l < NJ) ? row[k] : 0.f;
+            rr.R[3 * c + t] = (ok && l < NJ) ? row[24 + k] : 0.f;
+            rr.rhs[3 * c + t] = ok ? row[34] : 0.f;
+            rr.dinv[3 * c + t] = ok ? row[33] : 0.f;
+            rr.app[3 * c + t] = 0.f;
+        }
+        rr.mu[c] = c < nc ? L.rows[MAXC + 2 * c][35] : 0.f;
+    }
+}
+
+/* one PGS iteration over the contact rows (normals, then frictions of loaded normals) */
+template <int MAXC>
+__device__ __forceinline__ float robot_rows_iteration(RobotRows<MAXC>& rr, int nc, float& dv)
+{
+    float resid = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        if (c < nc) {
+            const int r = 3 * c;
+            float jd = wv::sum_row0(rr.J[r] * dv);
+            float napp = fmaxf(rr.app[r] + (rr.rhs[r] - jd * rr.dinv[r]), 0.f);
+            napp = fminf(napp, 1e10f);
+            float delta = napp - rr.app[r];
+            rr.app[r] = napp;
+            dv += rr.R[r] * delta;
+            float d = rr.dinv[r] != 0.f ? delta / rr.dinv[r] : 0.f;
+            resid = fmaxf(resid, d * d);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        if (c < nc && rr.app[3 * c] > 0.f) {
+            float lim = rr.mu[c] * rr.app[3 * c];
+#pragma unroll
+            for (int t = 1; t < 3; t++) {
+                const int r = 3 * c + t;
+                float jd = wv::sum_row0(rr.J[r] * dv);
+                float napp = __builtin_amdgcn_fmed3f(rr.app[r] + (rr.rhs[r] - jd * rr.dinv[r]), -lim, lim);
+                float delta = napp - rr.app[r];
+                rr.app[r] = napp;
+                dv += rr.R[r] * delta;
+                float d = rr.dinv[r] != 0.f ? delta / rr.dinv[r] : 0.f;
+                resid = fmaxf(resid, d * d);
+            }
+        }
+    }
+    return resid;
 }
 
 }  // namespace pmg

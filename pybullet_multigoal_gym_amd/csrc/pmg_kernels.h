@@ -9,7 +9,7 @@
 #include "pmg_contact.h"
 
 #ifndef PMG_COLD_CONTACTS
-#define PMG_COLD_CONTACTS 0 /* 1: keep the reach kernel's rare contact phases out of line */
+#define PMG_COLD_CONTACTS 1 /* keep the reach kernel's rare contact phases out of line (compact hot loop) */
 #endif
 
 namespace pmg {
@@ -220,6 +220,23 @@ __device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const floa
     else build_contact_rows(L, nc);
 }
 
+/* reach: PGS iterations when finger x table contacts exist -- register-resident rows (RobotRows) */
+template <int NB, int MAXC>
+__device__ __forceinline__ void reach_contact_pgs(ContactLds<NB, MAXC>& L, int nc, NcRows& r, const float* minv_in, float& dv)
+{
+    float minv[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) minv[j] = minv_in[j];
+    RobotRows<MAXC> rr;
+    load_robot_rows(L, nc, rr);
+    for (int it = 0; it < SOLVER_ITERS; it++) {
+        nc_sweep(r, (it & 1) != 0, minv, dv);
+        float resid = robot_rows_iteration(rr, nc, dv);
+        resid = fmaxf(resid, wv::max_row0(nc_residual(r)));
+        if (resid <= RESIDUAL_THRESHOLD) break;
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /* one 2 ms substep: collide, unconstrained velocities, PGS rows, integrate
  * ([BULLET-PRIOR] btMultiBodyDynamicsWorld::internalSingleStepSimulation)  */
@@ -271,11 +288,21 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
     PMG_TICK(2);
     if (nc > 0) prepare_rows<NB, MAXC>(L, minv, qd, nc);
     PMG_TICK(3);
-    ConRegs cr;
-    if (nc > 0) load_con_regs(L, nc, cr);
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
     float dv = 0.f; /* lanes 0..8: joint velocity change; lanes 16+8b+c: block b component c */
+    if (NB == 0) {
+        if (nc > 0) {
+            reach_contact_pgs<NB, MAXC>(L, nc, r, minv, dv);
+        } else {
+            for (int it = 0; it < SOLVER_ITERS; it++) {
+                nc_sweep(r, (it & 1) != 0, minv, dv);
+                if (wv::max_row0(nc_residual(r)) <= RESIDUAL_THRESHOLD) break;
+            }
+        }
+    } else {
+    ConRegs cr;
+    if (nc > 0) load_con_regs(L, nc, cr);
     for (int it = 0; it < SOLVER_ITERS; it++) {
         nc_sweep(r, (it & 1) != 0, minv, dv);
         float resid = 0.f;
@@ -290,6 +317,7 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
         }
         resid = fmaxf(resid, wv::max_row0(nc_residual(r)));
         if (resid <= RESIDUAL_THRESHOLD) break;
+    }
     }
     PMG_TICK(4);
     if (l < NJ) qd += dv;
