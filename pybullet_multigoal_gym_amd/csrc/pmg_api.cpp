@@ -271,6 +271,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipMalloc((void**)&e->P.blocks, N * pmg::BLOCK_DIM * (nb ? nb : 1) * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.rng, N * 625 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
+    CREATE_TRY(hipMalloc((void**)&e->P.sched, (2 + 2 * N) * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->d_mask, N));
     CREATE_TRY(hipHostMalloc((void**)&e->h_packed, N * dims.packed_dim * sizeof(float)));
@@ -301,7 +302,7 @@ void pmg_destroy(pmg_env* e)
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
-    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out);
+    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out); (void)hipFree(e->P.sched);
     (void)hipFree(e->d_actions); (void)hipFree(e->d_mask);
     (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
     if (e->h_packed) (void)hipHostFree(e->h_packed);

@@ -404,11 +404,17 @@ struct ContactLds {
     float qd[NJ];
     float minv[NJ][NJ];
     int pair_count[NPAIR];
-    float work[NPAIR][BOX_WORK];               /* box_box workspace per pair lane */
-    float stage[NPAIR][4][10];                 /* pa pb n dist per staged point */
     float con[MAXC][12];                       /* a b pa3 pb3 n3 dist -> [0]=a [1]=b [2..4]pa [5..7]pb [8..10]n [11]dist */
     float con_mu[MAXC];
-    float rows[3 * MAXC][ROW_STRIDE];
+    /* the narrowphase scratch (box_box workspace + staged points) is dead once the contacts are
+     * compacted into `con`, and the rows are built after that: they share storage */
+    union {
+        struct {
+            float work[NPAIR][BOX_WORK];       /* box_box workspace per pair lane */
+            float stage[NPAIR][4][10];         /* pa pb n dist per staged point */
+        };
+        float rows[3 * MAXC][ROW_STRIDE];
+    };
     int ncon;
 };
 

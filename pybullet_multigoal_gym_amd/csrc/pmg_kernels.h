@@ -35,6 +35,7 @@ struct EnvParams {
     float* blocks;   /* [N, BLOCK_DIM * nb] */
     unsigned* rng;   /* [N, 625] MT19937 state + index */
     float* out;      /* [N, packed]: obs | policy | ag | dg | reward | goal_achieved | done */
+    int* sched;      /* [2 + 2N]: counts of {contact-prone, other} envs, then the two env lists */
 #ifdef PMG_PROFILE
     long long* prof; /* per-phase wall_clock64 ticks of env 0 */
 #endif
@@ -354,13 +355,37 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
 }
 
 /* ------------------------------------------------------------------ */
+/* Launch-order plan.  A batched step lasts as long as its slowest wavefront, and the slow ones are
+ * the envs whose fingers will touch the table (contact phases, ~2.5x a contact-free substep).  The
+ * hardware favours the OLDEST wave of a SIMD, so those envs are given the lowest workgroup ids:
+ * dispatched first, one per SIMD, they run at single-wave speed from t = 0 while the rest fill the
+ * issue slots.  The mapping never changes a result (envs are independent), only who waits.     */
+__device__ __forceinline__ void plan_env(const EnvParams& P, const float* actions, int env)
+{
+    const float* hot = P.hot + (size_t)env * HOT_DIM;
+    bool prone = P.nb > 0 || P.joint_control;           /* blocks always touch the table */
+    if (!prone) {
+        float z = hot[20];                                /* tip target: the tip is within mm of it */
+        float zn = fminf(fmaxf(z + actions[(size_t)env * P.adim + 2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
+        prone = fminf(z, zn) < P.ee_lo[2] + 0.012f;
+    }
+    int slot = atomicAdd(&P.sched[prone ? 0 : 1], 1);
+    P.sched[2 + (prone ? 0 : P.n_envs) + slot] = env;
+}
+__device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
+{
+    int n0 = P.sched[0];
+    return block < n0 ? P.sched[2 + block] : P.sched[2 + P.n_envs + (block - n0)];
+}
+
+/* ------------------------------------------------------------------ */
 /* env.step(): kuka.py:167-225 + _get_obs + _compute_reward + TimeLimit */
 template <int NB, int MAXC>
 __device__ __forceinline__ void step_env(const EnvParams& P, const float* actions)
 {
     __shared__ ContactLds<NB, MAXC> L;
     __shared__ LaneTabStore lcs;
-    int env = (int)blockIdx.x, l = wv::lane();
+    int env = scheduled_env(P, (int)blockIdx.x), l = wv::lane();
     if (env >= P.n_envs) return;
     LaneConst c;
     load_lane_const(lcs, c);
