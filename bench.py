@@ -32,6 +32,23 @@ ALGO_BYTES = {'reach': 298, 'push': 486, 'pick_and_place': 490, 'block_stack': 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def committed_traffic(task, n_envs):
+    """HBM bytes per pmg_k_step launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, KiB -> bytes; the
+    guide's x2 FETCH correction applies to 16 B/lane streaming reads only -- these are dword accesses, so
+    the raw counters are reported).  None when no pass is committed for this workload."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get('task') == task and d.get('envs_per_gpu') == n_envs:
+            best = d
+    return None if best is None else float(best['hbm_bytes_per_launch'])
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -153,7 +170,7 @@ def main():
                                    'reset every %d steps, 100 substeps/env-step' % (args.task, N, T),
                        'global_envs': world * N, 'parallelism': 'env-shard x%d, RCCL all-gather of packed obs' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': committed_traffic(args.task, N),
                          'kernel': 'pmg_k_step', 'kernel_ms': kernel_ms, 'launches': launches,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES[args.task],
                          'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by '

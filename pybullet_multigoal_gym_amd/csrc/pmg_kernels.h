@@ -360,17 +360,49 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
  * hardware favours the OLDEST wave of a SIMD, so those envs are given the lowest workgroup ids:
  * dispatched first, one per SIMD, they run at single-wave speed from t = 0 while the rest fill the
  * issue slots.  The mapping never changes a result (envs are independent), only who waits.     */
-__device__ __forceinline__ void plan_env(const EnvParams& P, const float* actions, int env)
+__device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* actions, int env)
 {
+    if (P.nb > 0 || P.joint_control) return true;         /* blocks always touch the table */
     const float* hot = P.hot + (size_t)env * HOT_DIM;
-    bool prone = P.nb > 0 || P.joint_control;           /* blocks always touch the table */
-    if (!prone) {
-        float z = hot[20];                                /* tip target: the tip is within mm of it */
-        float zn = fminf(fmaxf(z + actions[(size_t)env * P.adim + 2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
-        prone = fminf(z, zn) < P.ee_lo[2] + 0.012f;
+    float z = hot[20];                                    /* tip target: the tip is within mm of it */
+    float zn = fminf(fmaxf(z + actions[(size_t)env * P.adim + 2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
+    return fminf(z, zn) < P.ee_lo[2] + 0.012f;
+}
+/* one 1024-thread workgroup partitions all envs (stable, no atomics): per-wave ballots, counts of
+ * every (chunk, wave) tile in LDS, then each tile scatters at its exclusive prefix */
+constexpr int PLAN_THREADS = 1024, PLAN_MAX_TILES = 1024;
+__device__ __forceinline__ void plan_all(const EnvParams& P, const float* actions)
+{
+    __shared__ int cnt0[PLAN_MAX_TILES], cnt1[PLAN_MAX_TILES];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = PLAN_THREADS / 64;
+    const int chunks = (P.n_envs + PLAN_THREADS - 1) / PLAN_THREADS;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int c = 0; c < chunks; c++) {
+        int env = c * PLAN_THREADS + tid;
+        bool valid = env < P.n_envs;
+        bool prone = valid && contact_prone(P, actions, env);
+        unsigned long long m0 = wv::ballot(prone), m1 = wv::ballot(valid && !prone);
+        if (lane == 0 && c * waves + wave < PLAN_MAX_TILES) { cnt0[c * waves + wave] = __popcll(m0); cnt1[c * waves + wave] = __popcll(m1); }
     }
-    int slot = atomicAdd(&P.sched[prone ? 0 : 1], 1);
-    P.sched[2 + (prone ? 0 : P.n_envs) + slot] = env;
+    __syncthreads();
+    const int tiles = chunks * waves < PLAN_MAX_TILES ? chunks * waves : PLAN_MAX_TILES;
+    for (int c = 0; c < chunks; c++) {
+        int tile = c * waves + wave;
+        int env = c * PLAN_THREADS + tid;
+        bool valid = env < P.n_envs && tile < PLAN_MAX_TILES;
+        bool prone = valid && contact_prone(P, actions, env);
+        unsigned long long m0 = wv::ballot(prone), m1 = wv::ballot(valid && !prone);
+        int b0 = 0, b1 = 0;
+        for (int t = 0; t < tile && t < tiles; t++) { b0 += cnt0[t]; b1 += cnt1[t]; }
+        if (prone) P.sched[2 + b0 + __popcll(m0 & below)] = env;
+        else if (valid) P.sched[2 + P.n_envs + b1 + __popcll(m1 & below)] = env;
+    }
+    if (tid == 0) {
+        int n0 = 0, n1 = 0;
+        for (int t = 0; t < tiles; t++) { n0 += cnt0[t]; n1 += cnt1[t]; }
+        P.sched[0] = n0;
+        P.sched[1] = n1;
+    }
 }
 __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
 {

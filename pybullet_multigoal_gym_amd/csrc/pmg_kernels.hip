@@ -18,10 +18,9 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParam
     pmg::step_env<NB, MAXC>(P, actions);
 }
 
-__global__ void __launch_bounds__(256) pmg_k_plan(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(1024) pmg_k_plan(pmg::EnvParams P, const float* __restrict__ actions)
 {
-    int env = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (env < P.n_envs) pmg::plan_env(P, actions, env);
+    pmg::plan_all(P, actions);
 }
 
 __global__ void __launch_bounds__(64) pmg_k_reset(pmg::EnvParams P, const unsigned char* __restrict__ mask)
@@ -48,11 +47,14 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
     if (ok) ok[i] = na ? 0 : 1;
 }
 
+hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
+{
+    /* contact tasks: every env is contact-prone, the identity schedule written at create time stays valid */
+    if (P.nb == 0 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    return hipGetLastError();
+}
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    hipError_t rc = hipMemsetAsync(P.sched, 0, 2 * sizeof(int), s);
-    if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(pmg_k_plan, dim3((P.n_envs + 255) / 256), dim3(256), 0, s, P, d_actions);
     if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     else if (P.nb == 1) hipLaunchKernelGGL((pmg_k_step<1, 24>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     else hipLaunchKernelGGL((pmg_k_step<5, 48>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "pmg_kernels.h"
 
+hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s);
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s);
 hipError_t pmg_launch_reset(const pmg::EnvParams& P, const unsigned char* d_mask, hipStream_t s);
 hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int G, float thr, int binary, float* reward,

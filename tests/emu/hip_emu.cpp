@@ -4,7 +4,7 @@
 #include <cstdio>
 
 emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
-float emu_xf[64 * 16];
+float emu_xf[16 * 64 * 16];
 
 namespace {
 constexpr size_t STACK_BYTES = 512 * 1024;

@@ -44,7 +44,7 @@ void emu_barrier();
 #define __syncthreads() emu_barrier()
 
 /* exchange buffer for cross-lane primitives */
-extern float emu_xf[64 * 16];
+extern float emu_xf[16 * 64 * 16]; /* [wave][slot][lane] */
 
 namespace emu {
 void launch(int grid, int block, const std::function<void()>& body);

@@ -6,17 +6,19 @@
 
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 
 namespace wv {
-inline int lane() { return (int)threadIdx.x; }
+inline int lane() { return (int)threadIdx.x & 63; }
+inline float* xbuf() { return emu_xf + ((int)threadIdx.x >> 6) * (64 * 16); } /* per-wave exchange area */
 inline void lds_sync() { emu_barrier(); }
 
 template <int N>
 inline void exchange_put(const float* v)
 {
-    for (int k = 0; k < N; k++) emu_xf[64 * k + lane()] = v[k];
+    for (int k = 0; k < N; k++) xbuf()[64 * k + lane()] = v[k];
     emu_barrier();
 }
 inline void exchange_done() { emu_barrier(); }
@@ -26,7 +28,7 @@ inline void bcastn(const float* v, int src, float* out)
 {
     exchange_put<N>(v);
     float t[N];
-    for (int k = 0; k < N; k++) t[k] = emu_xf[64 * k + src];
+    for (int k = 0; k < N; k++) t[k] = xbuf()[64 * k + src];
     exchange_done();
     for (int k = 0; k < N; k++) out[k] = t[k];
 }
@@ -43,7 +45,7 @@ inline float permute(float v, float fill, F srcfn)
 {
     exchange_put<1>(&v);
     int s = srcfn(lane());
-    float r = s >= 0 ? emu_xf[s] : fill;
+    float r = s >= 0 ? xbuf()[s] : fill;
     exchange_done();
     return r;
 }
@@ -65,7 +67,7 @@ inline float row_sum(float v)
     /* same association order as the DPP butterfly: ((a+b)+(c+d)) pairs, then halves */
     float q[4];
     for (int g = 0; g < 4; g++) {
-        float a = emu_xf[b + 4 * g], bb = emu_xf[b + 4 * g + 1], c = emu_xf[b + 4 * g + 2], d = emu_xf[b + 4 * g + 3];
+        float a = xbuf()[b + 4 * g], bb = xbuf()[b + 4 * g + 1], c = xbuf()[b + 4 * g + 2], d = xbuf()[b + 4 * g + 3];
         q[g] = (a + bb) + (c + d);
     }
     s = (q[0] + q[1]) + (q[2] + q[3]);
@@ -76,8 +78,8 @@ inline float row_max(float v)
 {
     exchange_put<1>(&v);
     int b = lane() & ~15;
-    float s = emu_xf[b];
-    for (int k = 1; k < 16; k++) s = fmaxf(s, emu_xf[b + k]);
+    float s = xbuf()[b];
+    for (int k = 1; k < 16; k++) s = fmaxf(s, xbuf()[b + k]);
     exchange_done();
     return s;
 }
@@ -101,7 +103,7 @@ inline unsigned long long ballot(bool p)
     exchange_put<1>(&f);
     unsigned long long m = 0;
     for (int k = 0; k < 64; k++)
-        if (emu_xf[k] != 0.f) m |= 1ull << k;
+        if (xbuf()[k] != 0.f) m |= 1ull << k;
     exchange_done();
     return m;
 }
