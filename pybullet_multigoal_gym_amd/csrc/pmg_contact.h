@@ -22,10 +22,22 @@ constexpr float BLOCK_MASS = (float)PMG_BLOCK_MASS;
 constexpr float BLOCK_INERTIA = 0.0009f;      /* isotropic cube: PMG_BLOCK_INERTIA */
 constexpr float BLOCK_HALF = 0.015f;
 constexpr float FINGER_RADIUS = 0.0431f;      /* bounding sphere of the finger box + slack (oracle cull) */
-constexpr int ROW_STRIDE = 40;                /* floats per constraint row in LDS */
-/* row layout: [0..8] J robot, [9..14] J block slot A, [15..20] J block slot B, [21..23] pad,
- *             [24..32] M^-1 J^T robot, [33] dinv, [34] rhs, [35] mu (friction rows), [36] applied,
- *             [37] block id A (or -1), [38] block id B (or -1), [39] has_robot */
+constexpr int ROW_STRIDE = 40;                /* floats per constraint row in LDS (160 B: rows stay 16 B aligned) */
+/* Row layouts.  SLOT (reach, block_stack): the Jacobian of at most two blocks sits in two slots and a
+ * lane looks its slot up.  DIRECT (one free object: push / pick_and_place): lane l < 16 reads J[l]
+ * and (M^-1 J^T)[l] straight from the row -- lanes 0..8 robot DoFs, lanes 9..14 the object's
+ * [v, w] -- so a visit is two coalesced LDS reads, one DPP butterfly in row 0 and no lane lookup.
+ *   SLOT  : [0..8] J robot | [9..14] J slot A | [15..20] J slot B | [21] id A | [22] id B | [23..31] M^-1J^T robot
+ *   DIRECT: [0..8] J robot | [9..14] J object | [15] 0 | [16..24] M^-1J^T robot | [25..30] resp object | [31] 0
+ *   both  : [32] rhs [33] 1/diag [34] applied impulse [35] mu (16 B aligned: one ds_read_b128)
+ *           [36..38] direction (scratch of the row build) [39] has_robot                                  */
+constexpr int ROW_SC = 32, ROW_RHS = 32, ROW_DINV = 33, ROW_APP = 34, ROW_MU = 35, ROW_DIR = 36, ROW_HASROB = 39;
+constexpr int SLOT_IDA = 21, SLOT_IDB = 22;
+template <int NB>
+struct RowLayout {
+    static constexpr bool direct = NB == 1;
+    static constexpr int R_OFF = direct ? 16 : 23; /* start of M^-1 J^T (robot part) */
+};
 
 struct BoxPose { float c[3]; float R[9]; };
 
@@ -518,6 +530,7 @@ __device__ __forceinline__ float* row_of(ContactLds<NB, MAXC>& L, int c, int t)
 template <int NB, int MAXC>
 __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int nc)
 {
+    using LY = RowLayout<NB>;
     int l = wv::lane();
     /* R1 */
     for (int c = l; c < nc; c += 64) {
@@ -529,9 +542,9 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
             float* row = row_of(L, c, t);
             const float* dir = t == 0 ? n : (t == 1 ? t1 : t2);
             for (int k = 0; k < ROW_STRIDE; k++) row[k] = 0.f;
-            row[21] = dir[0]; row[22] = dir[1]; row[23] = dir[2]; /* pad slots carry the direction to R2 */
+            row[ROW_DIR] = dir[0]; row[ROW_DIR + 1] = dir[1]; row[ROW_DIR + 2] = dir[2];
             float denom = 0.f, rel = 0.f;
-            row[37] = -1.f; row[38] = -1.f;
+            if (!LY::direct) { row[SLOT_IDA] = -1.f; row[SLOT_IDB] = -1.f; }
             for (int s2 = 0; s2 < 2; s2++) {
                 int id = s2 == 0 ? a : b;
                 if (id < 0 || id >= BODY_FINGER1) continue;
@@ -540,15 +553,19 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
                 const float* bl = L.blk[id];
                 float r[3] = {pt[0] - bl[0], pt[1] - bl[1], pt[2] - bl[2]}, rxn[3];
                 cross3(r, dir, rxn);
-                float* J = row + 9 + 6 * s2;
+                float* J = row + 9 + (LY::direct ? 0 : 6 * s2);
                 for (int k = 0; k < 3; k++) { J[k] = sg * dir[k]; J[3 + k] = sg * rxn[k]; }
-                row[37 + s2] = (float)id;
+                if (LY::direct) {
+                    for (int k = 0; k < 3; k++) { row[25 + k] = J[k] / BLOCK_MASS; row[28 + k] = J[3 + k] / BLOCK_INERTIA; }
+                } else {
+                    row[SLOT_IDA + s2] = (float)id;
+                }
                 denom += dot3(J, J) / BLOCK_MASS + dot3(J + 3, J + 3) / BLOCK_INERTIA;
                 rel += dot3(J, bl + 7) + dot3(J + 3, bl + 10);
             }
-            row[33] = denom;
-            row[34] = rel;
-            row[39] = (a >= BODY_FINGER1 || b >= BODY_FINGER1) ? 1.f : 0.f;
+            row[ROW_DINV] = denom;
+            row[ROW_RHS] = rel;
+            row[ROW_HASROB] = (a >= BODY_FINGER1 || b >= BODY_FINGER1) ? 1.f : 0.f;
         }
     }
     wv::lds_sync();
@@ -568,7 +585,7 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
             float v[3];
             cross3(S, pt, v);
             v[0] += S[3]; v[1] += S[4]; v[2] += S[5];
-            acc += (s2 == 0 ? 1.f : -1.f) * (v[0] * row[21] + v[1] * row[22] + v[2] * row[23]);
+            acc += (s2 == 0 ? 1.f : -1.f) * (v[0] * row[ROW_DIR] + v[1] * row[ROW_DIR + 1] + v[2] * row[ROW_DIR + 2]);
         }
         row[d] = acc;
     }
@@ -577,11 +594,11 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
     for (int item = l; item < 27 * nc; item += 64) {
         int c = item / 27, t = (item / 9) % 3, i = item % 9;
         float* row = row_of(L, c, t);
-        if (row[39] != 0.f) {
-            float s = 0.f;
+        if (row[ROW_HASROB] != 0.f) {
+            float s2 = 0.f;
 #pragma unroll
-            for (int j = 0; j < NJ; j++) s += L.minv[i][j] * row[j];
-            row[24 + i] = s;
+            for (int j = 0; j < NJ; j++) s2 += L.minv[i][j] * row[j];
+            row[LY::R_OFF + i] = s2;
         }
     }
     wv::lds_sync();
@@ -590,92 +607,127 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
         float dist = L.con[c][11] + LINEAR_SLOP;
         for (int t = 0; t < 3; t++) {
             float* row = row_of(L, c, t);
-            float denom = row[33], rel = row[34];
-            if (row[39] != 0.f) {
+            float denom = row[ROW_DINV], rel = row[ROW_RHS];
+            if (row[ROW_HASROB] != 0.f) {
 #pragma unroll
-                for (int d = 0; d < NJ; d++) { denom += row[d] * row[24 + d]; rel += row[d] * L.qd[d]; }
+                for (int d = 0; d < NJ; d++) { denom += row[d] * row[LY::R_OFF + d]; rel += row[d] * L.qd[d]; }
             }
             float dinv = denom > SIMD_EPS ? 1.f / denom : 0.f;
-            row[33] = dinv;
+            row[ROW_DINV] = dinv;
+            row[ROW_APP] = 0.f;
             if (t == 0) {
                 float pos_err = 0.f, vel_err = -rel;
                 if (dist > 0.f) vel_err -= dist / DT;
                 else pos_err = -dist * CONTACT_ERP / DT;
-                row[34] = (pos_err + vel_err) * dinv;
+                row[ROW_RHS] = (pos_err + vel_err) * dinv;
+                row[ROW_MU] = 0.f;
             } else {
-                row[34] = -rel * dinv;
-                row[35] = L.con_mu[c];
+                row[ROW_RHS] = -rel * dinv;
+                row[ROW_MU] = L.con_mu[c];
             }
-            row[21] = row[22] = row[23] = 0.f;
         }
     }
     wv::lds_sync();
 }
 
-/* this lane's slot in a row's Jacobian (or -1), and its response scale for block DoFs */
-__device__ __forceinline__ int lane_slot(int l, int ida, int idb, float& scale)
-{
-    scale = 0.f;
-    if (l < NJ) return l;
-    if (l < 16) return -1;
-    int b = (l - 16) >> 3, c = (l - 16) & 7;
-    if (c >= 6) return -1;
-    scale = c < 3 ? 1.f / BLOCK_MASS : 1.f / BLOCK_INERTIA;
-    if (b == ida) return 9 + c;
-    if (b == idb) return 15 + c;
-    return -1;
-}
-
-/* per-lane registers of the contact rows: lane c owns the scalars of contact c's normal row and
- * of its two friction rows (right-hand side, 1/diag, accumulated impulse), so that a visit needs
- * only v_readlane broadcasts plus the two per-lane LDS reads of J and M^-1 J^T -- and no LDS
- * store, which lets the loads of the next visit issue early. */
-struct ConRegs {
-    float dinv[3], rhs[3], app[3]; /* [0] normal, [1..2] friction */
-    float mu;
-    int ida, idb;
+/* ---------------------------------------------------------------- */
+/* Gauss-Seidel visit of one LDS row (kernels with free bodies).  All row scalars are one 16-byte
+ * uniform LDS read, J and the response are per-lane LDS reads, the accumulated impulse goes back
+ * with one store: no v_readlane / SGPR round trips on the critical path of the solve, which is
+ * VALU-issue bound when every env of the batch is in contact.                                  */
+template <int NB>
+struct LaneDof { /* which DoF of the constraint space this lane holds during the solve */
+    int blk, comp;   /* block index / component (0..5), or -1 */
+    float scale;     /* response scale of a block DoF: 1/m (linear) or 1/I (angular) */
 };
-
-template <int NB, int MAXC>
-__device__ __forceinline__ void load_con_regs(ContactLds<NB, MAXC>& L, int nc, ConRegs& r)
-{
-    int c = wv::lane();
-    bool ok = c < nc;
-    int cc = ok ? c : 0;
-    const float* rn = L.rows[cc];
-    r.dinv[0] = ok ? rn[33] : 0.f; r.rhs[0] = ok ? rn[34] : 0.f; r.app[0] = 0.f;
-    r.ida = ok ? (int)rn[37] : -1; r.idb = ok ? (int)rn[38] : -1;
-#pragma unroll
-    for (int f = 0; f < 2; f++) {
-        const float* rf = L.rows[MAXC + 2 * cc + f];
-        r.dinv[1 + f] = ok ? rf[33] : 0.f; r.rhs[1 + f] = ok ? rf[34] : 0.f; r.app[1 + f] = 0.f;
-    }
-    r.mu = ok ? L.rows[MAXC + 2 * cc][35] : 0.f;
-}
-
-/* one Gauss-Seidel visit of row K (0 normal, 1/2 friction) of contact c (wave-uniform);
- * dv is this lane's delta-velocity DoF.  Returns the velocity change for the residual test. */
-template <int K>
-__device__ __forceinline__ float contact_row_solve(const float* row, int c, ConRegs& r, float& dv)
+template <int NB>
+__device__ __forceinline__ void lane_dof(LaneDof<NB>& d)
 {
     int l = wv::lane();
-    float pk[4] = {r.rhs[K], r.dinv[K], r.app[K], K == 0 ? 0.f : r.mu * r.app[0]}, o[4];
-    wv::bcastn<4>(pk, c, o);
-    int ida = wv::bcast_i(r.ida, c), idb = wv::bcast_i(r.idb, c);
-    float lo = K == 0 ? 0.f : -o[3], hi = K == 0 ? 1e10f : o[3];
-    if (K != 0 && !(o[3] > 0.f)) return 0.f; /* friction rows wait for a positive normal impulse */
-    float scale;
-    int slot = lane_slot(l, ida, idb, scale);
-    float J = slot >= 0 ? row[slot] : 0.f;
-    float resp = l < NJ ? row[24 + l] : J * scale;
-    /* rows without block DoFs (finger x table) live entirely in lanes 0..8: one DPP butterfly */
-    float jd = (ida < 0 && idb < 0) ? wv::sum_row0(J * dv) : wv::sum_all(J * dv);
-    float sum = o[2] + (o[0] - jd * o[1]);
-    float napp = __builtin_amdgcn_fmed3f(sum, lo, hi);
-    float delta = napp - o[2];
-    if (l == c) r.app[K] = napp;
-    dv += resp * delta;
-    return delta * (o[1] != 0.f ? 1.f / o[1] : 0.f);
+    d.blk = -1; d.comp = -1; d.scale = 0.f;
+    if (l >= NJ && l < NJ + 6 * NB) {
+        d.blk = (l - NJ) / 6;
+        d.comp = (l - NJ) % 6;
+        d.scale = d.comp < 3 ? 1.f / BLOCK_MASS : 1.f / BLOCK_INERTIA;
+    }
+}
+
+/* what one visit needs from LDS; fetched one visit AHEAD (software pipelining): none of it depends on
+ * the running delta-velocity, so the ~100-cycle LDS latency hides behind the previous row's reduction */
+struct RowData {
+    float J, resp, rhs, dinv, app;
+};
+template <int NB>
+__device__ __forceinline__ void row_fetch(const float* row, const LaneDof<NB>& ld, RowData& d)
+{
+    using LY = RowLayout<NB>;
+    int l = wv::lane();
+    if (LY::direct) {
+        d.J = l < 16 ? row[l] : 0.f;
+        d.resp = l < 16 ? row[16 + l] : 0.f;
+    } else {
+        int ida = (int)row[SLOT_IDA], idb = (int)row[SLOT_IDB];
+        int slot = l < NJ ? l : (ld.blk >= 0 ? (ld.blk == ida ? 9 + ld.comp : (ld.blk == idb ? 15 + ld.comp : -1)) : -1);
+        d.J = slot >= 0 ? row[slot] : 0.f;
+        d.resp = l < NJ ? row[LY::R_OFF + l] : d.J * ld.scale;
+    }
+    d.rhs = row[ROW_RHS];
+    d.dinv = row[ROW_DINV];
+    d.app = row[ROW_APP];
+}
+
+/* K = 0 normal row (bounds [0, 1e10]), K = 1 friction row (bounds +-lim, lim wave-uniform).
+ * dv: this lane's delta-velocity DoF; returns the squared velocity change (valid in DoF lanes). */
+template <int NB, int K>
+__device__ __forceinline__ float lds_row_solve(float* row, const RowData& rd, float lim, float& dv)
+{
+    using LY = RowLayout<NB>;
+    int l = wv::lane();
+    float x = rd.J * dv;
+    float jd;
+    if (LY::direct) jd = wv::row_sum(x);                 /* every DoF lives in lanes 0..14: row-local, no broadcast */
+    else jd = wv::sum_rows<(NJ + 6 * NB + 15) / 16>(x);
+    float sum = rd.app + (rd.rhs - jd * rd.dinv);
+    float napp = K == 0 ? fminf(fmaxf(sum, 0.f), 1e10f) : __builtin_amdgcn_fmed3f(sum, -lim, lim);
+    float delta = napp - rd.app;
+    if (l == 0) row[ROW_APP] = napp;
+    dv += rd.resp * delta;
+    float d = rd.dinv != 0.f ? delta / rd.dinv : 0.f;
+    if (LY::direct && l >= 16) d = 0.f; /* only row 0 computed the real impulse */
+    return d * d;
+}
+
+/* one PGS iteration over the LDS contact rows: normals in list order, then the friction pairs of
+ * the contacts that carry a positive normal impulse ([BULLET-PRIOR] solveSingleIteration).
+ * `loaded` (wave-uniform bit mask) records which normals ended the pass with a positive impulse,
+ * so the friction pass branches on scalar bits instead of LDS round trips. */
+template <int NB, int MAXC>
+__device__ __forceinline__ float lds_rows_iteration(ContactLds<NB, MAXC>& L, int nc, const LaneDof<NB>& ld, float& dv)
+{
+    float resid = 0.f;
+    unsigned long long loaded = 0ull;
+    RowData cur, nxt;
+    row_fetch<NB>(L.rows[0], ld, cur);
+    for (int cc = 0; cc < nc; cc++) {
+        row_fetch<NB>(L.rows[cc + 1 < nc ? cc + 1 : cc], ld, nxt);
+        resid = fmaxf(resid, lds_row_solve<NB, 0>(L.rows[cc], cur, 0.f, dv));
+        cur = nxt;
+    }
+    /* which normals carry an impulse now: one uniform LDS read each, folded into a scalar mask */
+    for (int cc = 0; cc < nc; cc++)
+        if (wv::uniform_positive(L.rows[cc][ROW_APP])) loaded |= 1ull << cc;
+    while (loaded) {
+        int cc = __builtin_ctzll(loaded);
+        loaded &= loaded - 1ull;
+        float* r1 = L.rows[MAXC + 2 * cc];
+        float lim = r1[ROW_MU] * L.rows[cc][ROW_APP];
+        RowData a, b;
+        row_fetch<NB>(r1, ld, a);
+        row_fetch<NB>(r1 + ROW_STRIDE, ld, b);
+        resid = fmaxf(resid, lds_row_solve<NB, 1>(r1, a, lim, dv));
+        resid = fmaxf(resid, lds_row_solve<NB, 1>(r1 + ROW_STRIDE, b, lim, dv));
+    }
+    return resid;
 }
 
 /* ---------------------------------------------------------------- */
@@ -702,12 +754,12 @@ __device__ __forceinline__ void load_robot_rows(ContactLds<NB, MAXC>& L, int nc,
             const float* row = t == 0 ? L.rows[c] : L.rows[MAXC + 2 * c + (t - 1)];
             bool ok = c < nc;
             rr.J[3 * c + t] = (ok && l < NJ) ? row[k] : 0.f;
-            rr.R[3 * c + t] = (ok && l < NJ) ? row[24 + k] : 0.f;
-            rr.rhs[3 * c + t] = ok ? row[34] : 0.f;
-            rr.dinv[3 * c + t] = ok ? row[33] : 0.f;
+            rr.R[3 * c + t] = (ok && l < NJ) ? row[RowLayout<NB>::R_OFF + k] : 0.f;
+            rr.rhs[3 * c + t] = ok ? row[ROW_RHS] : 0.f;
+            rr.dinv[3 * c + t] = ok ? row[ROW_DINV] : 0.f;
             rr.app[3 * c + t] = 0.f;
         }
-        rr.mu[c] = c < nc ? L.rows[MAXC + 2 * c][35] : 0.f;
+        rr.mu[c] = c < nc ? L.rows[MAXC + 2 * c][ROW_MU] : 0.f;
     }
 }
 

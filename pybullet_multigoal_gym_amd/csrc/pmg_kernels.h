@@ -291,7 +291,7 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
     PMG_TICK(3);
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
-    float dv = 0.f; /* lanes 0..8: joint velocity change; lanes 16+8b+c: block b component c */
+    float dv = 0.f; /* lanes 0..8: joint velocity change; lanes 9+6b+c: component c of block b */
     if (NB == 0) {
         if (nc > 0) {
             reach_contact_pgs<NB, MAXC>(L, nc, r, minv, dv);
@@ -302,32 +302,24 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
             }
         }
     } else {
-    ConRegs cr;
-    if (nc > 0) load_con_regs(L, nc, cr);
-    for (int it = 0; it < SOLVER_ITERS; it++) {
-        nc_sweep(r, (it & 1) != 0, minv, dv);
-        float resid = 0.f;
-        for (int cc = 0; cc < nc; cc++) {
-            float d = contact_row_solve<0>(L.rows[cc], cc, cr, dv);
-            resid = fmaxf(resid, d * d);
+        LaneDof<NB> ld;
+        lane_dof(ld);
+        for (int it = 0; it < SOLVER_ITERS; it++) {
+            PMG_TICK(10);
+            nc_sweep(r, (it & 1) != 0, minv, dv);
+            PMG_TICK(8);
+            float resid = nc > 0 ? lds_rows_iteration(L, nc, ld, dv) : 0.f;
+            PMG_TICK(9);
+            resid = fmaxf(resid, nc_residual(r));
+            /* residuals are per lane (valid where the DoFs live): one reduction per iteration */
+            if (wv::max_all(resid) <= RESIDUAL_THRESHOLD) break;
         }
-        for (int cc = 0; cc < nc; cc++) {
-            float d1 = contact_row_solve<1>(L.rows[MAXC + 2 * cc], cc, cr, dv);
-            float d2 = contact_row_solve<2>(L.rows[MAXC + 2 * cc + 1], cc, cr, dv);
-            resid = fmaxf(resid, fmaxf(d1 * d1, d2 * d2));
-        }
-        resid = fmaxf(resid, wv::max_row0(nc_residual(r)));
-        if (resid <= RESIDUAL_THRESHOLD) break;
-    }
     }
     PMG_TICK(4);
     if (l < NJ) qd += dv;
     q += DT * qd;
     if (NB > 0) {
-        if (l >= 16) {
-            int b = (l - 16) >> 3, cc = (l - 16) & 7;
-            if (b < nb && cc < 6) L.blk[b][7 + cc] += dv;
-        }
+        if (l >= NJ && l < NJ + 6 * nb) L.blk[(l - NJ) / 6][7 + (l - NJ) % 6] += dv;
         wv::lds_sync();
         if (l < nb) {
             float* b = L.blk[l];

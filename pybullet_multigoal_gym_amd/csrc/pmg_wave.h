@@ -69,6 +69,16 @@ __device__ __forceinline__ float row_max(float v)
 /* sum over lanes 0..15 only (robot DoFs live there), uniform result */
 __device__ __forceinline__ float sum_row0(float v) { return bcast(row_sum(v), 0); }
 __device__ __forceinline__ float max_row0(float v) { return bcast(row_max(v), 0); }
+/* sum over the first NR 16-lane rows, uniform result */
+template <int NR>
+__device__ __forceinline__ float sum_rows(float v)
+{
+    v = row_sum(v);
+    float s = bcast(v, 0);
+#pragma unroll
+    for (int r = 1; r < NR; r++) s += bcast(v, 16 * r);
+    return s;
+}
 /* sum over all 64 lanes, uniform result */
 __device__ __forceinline__ float sum_all(float v)
 {
@@ -81,6 +91,8 @@ __device__ __forceinline__ float max_all(float v)
     return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
 }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+/* v holds the same value in every lane: test v > 0 on the scalar unit (one v_readfirstlane) */
+__device__ __forceinline__ bool uniform_positive(float v) { return __builtin_amdgcn_readfirstlane(__float_as_int(v)) > 0; }
 /* optimisation barrier on a per-lane index: everything loaded through it is re-loaded */
 __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
 

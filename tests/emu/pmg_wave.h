@@ -85,6 +85,14 @@ inline float row_max(float v)
 }
 inline float sum_row0(float v) { return bcast(row_sum(v), 0); }
 inline float max_row0(float v) { return bcast(row_max(v), 0); }
+template <int NR>
+inline float sum_rows(float v)
+{
+    v = row_sum(v);
+    float s = bcast(v, 0);
+    for (int r = 1; r < NR; r++) s += bcast(v, 16 * r);
+    return s;
+}
 inline float sum_all(float v)
 {
     v = row_sum(v);
@@ -97,6 +105,7 @@ inline float max_all(float v)
     return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
 }
 inline void opaque(int& i) { (void)i; }
+inline bool uniform_positive(float v) { return v > 0.f; }
 inline unsigned long long ballot(bool p)
 {
     float f = p ? 1.f : 0.f;

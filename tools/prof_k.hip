@@ -35,7 +35,7 @@ int main(int argc, char** argv)
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         long long pr[16]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
-        printf("task %d rep %d kernel %.3f ms | ticks/substep (100MHz): fk %.0f detect %.0f dyn %.0f rows %.0f pgs %.0f | whole-step ticks: ik %lld loop %lld out %lld\n", task, rep, ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5], pr[6], pr[7]);
+        printf("task %d rep %d kernel %.3f ms | ticks/substep (100MHz): fk %.0f detect %.0f dyn %.0f rows %.0f pgs %.0f | whole-step ticks: ik %lld loop %lld out %lld | nc %.0f con %.0f\n", task, rep, ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5], pr[6], pr[7], pr[8]/100., pr[9]/100.);
     }
     std::vector<float> h2(N*32); hipMemcpy(h2.data(), P.hot, h2.size()*4, hipMemcpyDeviceToHost); printf("q0 after: %f %f %f ee z %f\n", h2[1], h2[3], h2[5], h2[20]);
     return 0;
