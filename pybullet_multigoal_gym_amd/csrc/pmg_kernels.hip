@@ -29,12 +29,37 @@ __global__ void __launch_bounds__(64) pmg_k_reset(pmg::EnvParams P, const unsign
 }
 
 /* _compute_reward on [B, G] batches (HER relabelling): kuka_single_step_base_env.py:237-244.
- * HBM-bound: 2*G*4 bytes in, 5 bytes out per item; one thread per item, rows are contiguous. */
-__global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag, const float* __restrict__ dg, long long B,
-                                                   int G, float thr, int binary, float* __restrict__ reward,
+ * HBM-bound: 2*G*4 bytes in, 5 bytes out per item.  G == 3 (every single-object task): one thread
+ * owns 4 consecutive items = 3 x 16-byte loads per array (fully coalesced dwordx4), one dwordx4
+ * store of rewards and one dword of flags; grid-stride over a bounded grid (Guideline 11/13). */
+__global__ void __launch_bounds__(256) pmg_k_reward3(const float4* __restrict__ ag, const float4* __restrict__ dg, long long quads,
+                                                    float thr, int binary, float4* __restrict__ reward,
+                                                    unsigned int* __restrict__ ok)
+{
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long long)gridDim.x * blockDim.x) {
+        float4 a0 = ag[3 * q], a1 = ag[3 * q + 1], a2 = ag[3 * q + 2];
+        float4 d0 = dg[3 * q], d1 = dg[3 * q + 1], d2 = dg[3 * q + 2];
+        float e[12] = {a0.x - d0.x, a0.y - d0.y, a0.z - d0.z, a0.w - d0.w, a1.x - d1.x, a1.y - d1.y,
+                       a1.z - d1.z, a1.w - d1.w, a2.x - d2.x, a2.y - d2.y, a2.z - d2.z, a2.w - d2.w};
+        float r[4];
+        unsigned int flags = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float d = sqrtf(e[3 * i] * e[3 * i] + e[3 * i + 1] * e[3 * i + 1] + e[3 * i + 2] * e[3 * i + 2]);
+            bool na = d > thr;
+            r[i] = binary ? (na ? -1.f : -0.f) : -d;
+            flags |= (na ? 0u : 1u) << (8 * i);
+        }
+        if (reward) reward[q] = make_float4(r[0], r[1], r[2], r[3]);
+        if (ok) ok[q] = flags;
+    }
+}
+/* any G, and the < 4 tail items of the G == 3 path */
+__global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag, const float* __restrict__ dg, long long first,
+                                                   long long B, int G, float thr, int binary, float* __restrict__ reward,
                                                    unsigned char* __restrict__ ok)
 {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long i = first + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     float s = 0.f;
     for (int g = 0; g < G; g++) {
@@ -69,7 +94,19 @@ hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int 
                              unsigned char* ok, hipStream_t s)
 {
     if (B <= 0) return hipSuccess;
-    unsigned grid = (unsigned)((B + 255) / 256);
-    hipLaunchKernelGGL(pmg_k_reward, dim3(grid), dim3(256), 0, s, ag, dg, B, G, thr, binary, reward, ok);
+    long long first = 0;
+    bool aligned = ((((size_t)ag | (size_t)dg | (size_t)reward) & 15) == 0) && (((size_t)ok & 3) == 0);
+    if (G == 3 && aligned && B >= 4) {
+        long long quads = B / 4;
+        long long want = (quads + 255) / 256;
+        unsigned grid = (unsigned)(want < 4096 ? want : 4096); /* 256 CUs x 16 blocks, grid-stride the rest */
+        hipLaunchKernelGGL(pmg_k_reward3, dim3(grid), dim3(256), 0, s, (const float4*)ag, (const float4*)dg, quads, thr, binary,
+                           (float4*)reward, (unsigned int*)ok);
+        first = quads * 4;
+    }
+    if (first < B) {
+        unsigned grid = (unsigned)((B - first + 255) / 256);
+        hipLaunchKernelGGL(pmg_k_reward, dim3(grid), dim3(256), 0, s, ag, dg, first, B, G, thr, binary, reward, ok);
+    }
     return hipGetLastError();
 }
