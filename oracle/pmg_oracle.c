@@ -75,6 +75,7 @@ typedef double real;
 #define IK_DAMPING ((real)0.5)         /* [BULLET-PRIOR] default joint_damping in calculateInverseKinematics */
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0)) /* [BULLET-PRIOR] MaxAngleDLS */
 #define CONTACT_MARGIN ((real)0.002)   /* build choice: speculative-contact distance */
+#define GBASE_FRICTION ((real)0.5)     /* [BULLET-PRIOR] btCollisionObject default friction (no <contact> tag) */
 #define EDGE_FUDGE ((real)1.05)        /* [BULLET-PRIOR] btBoxBoxDetector fudge_factor */
 #define MAX_CONTACTS 64
 #define PI_R ((real)3.14159265358979323846)
@@ -928,6 +929,256 @@ static int box_box(const real* ca, const real* Ra, const real* ha, const real* c
     return ns;
 }
 
+/* ------------------------------------------------------------------ */
+/* cylinder (A) x box (B) narrowphase.  Bullet runs GJK/EPA (btConvexConvexAlgorithm) and lets the
+ * persistent manifold collect up to 4 points over frames; this restatement regenerates a <= 4 point
+ * manifold every substep from a finite separating-axis search (3 box face normals, the cylinder
+ * axis, 3 axis x edge directions, 1 closest-feature axis) and feature clipping:
+ *   box face + cap parallel  -> rim points inside the face and face corners inside the disc
+ *   box face + side          -> the two ends of the deepest generator, clamped to the face
+ *   cylinder axis            -> box vertices on the supporting feature that lie inside the disc
+ *   edge / closest-feature   -> one point from the closest points of axis segment and box
+ * (build choice).  n points from the box to the cylinder.                */
+static real box_proj(const real (*B)[3], const real* hb, const real* L)
+{
+    return hb[0] * RFABS(v3dot(B[0], L)) + hb[1] * RFABS(v3dot(B[1], L)) + hb[2] * RFABS(v3dot(B[2], L));
+}
+static void closest_on_box(const real* cb, const real (*B)[3], const real* hb, const real* p, real* q)
+{
+    real d[3];
+    v3sub(d, p, cb);
+    v3cpy(q, cb);
+    for (int k = 0; k < 3; k++) {
+        real t = v3dot(d, B[k]);
+        t = t < -hb[k] ? -hb[k] : (t > hb[k] ? hb[k] : t);
+        v3axpy(q, t, B[k]);
+    }
+}
+static int reduce4(const real (*pts)[3], const real* sep, int m, int* sel)
+{
+    if (m <= 4) { for (int c = 0; c < m; c++) sel[c] = c; return m; }
+    int i0 = 0;
+    for (int c = 1; c < m; c++) if (sep[c] < sep[i0]) i0 = c;
+    int i1 = -1; real bd = -1;
+    for (int c = 0; c < m; c++) {
+        if (c == i0) continue;
+        real d[3]; v3sub(d, pts[c], pts[i0]);
+        real dd = v3dot(d, d);
+        if (dd > bd) { bd = dd; i1 = c; }
+    }
+    int i2 = -1, i3 = -1; real amax = 0, amin = 0;
+    real e[3]; v3sub(e, pts[i1], pts[i0]);
+    real ref[3] = {0, 0, 0};
+    for (int c = 0; c < m; c++) {
+        if (c == i0 || c == i1) continue;
+        real f[3], x[3]; v3sub(f, pts[c], pts[i0]); v3cross(x, e, f);
+        if (v3dot(ref, ref) == 0 && v3dot(x, x) > 0) v3cpy(ref, x);
+        real ar = v3dot(x, ref);
+        if (ar > amax) { amax = ar; i2 = c; }
+        if (ar < amin) { amin = ar; i3 = c; }
+    }
+    int ns = 0;
+    sel[ns++] = i0; sel[ns++] = i1;
+    if (i2 >= 0) sel[ns++] = i2;
+    if (i3 >= 0) sel[ns++] = i3;
+    return ns;
+}
+static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real* cb, const real* Rb, const real* hb,
+                   real margin, CPoint* out)
+{
+    real a[3] = {Rc[2], Rc[5], Rc[8]}, u[3] = {Rc[0], Rc[3], Rc[6]}, v[3] = {Rc[1], Rc[4], Rc[7]};
+    real B[3][3];
+    for (int k = 0; k < 3; k++) for (int x = 0; x < 3; x++) B[k][x] = Rb[3 * x + k];
+    real d[3];
+    v3sub(d, cc, cb);
+    real best = (real)-1e30, bn[3] = {0, 0, 0};
+    int btype = -1, bk = 0;
+    /* type 0: box faces, 1: cylinder axis, 2: axis x edge, 3: closest feature */
+    for (int pass = 0; pass < 8; pass++) {
+        real L[3];
+        int type, k = 0;
+        if (pass < 3) { type = 0; k = pass; v3cpy(L, B[k]); }
+        else if (pass == 3) { type = 1; v3cpy(L, a); }
+        else if (pass < 7) {
+            type = 2; k = pass - 4;
+            v3cross(L, a, B[k]);
+            real len = v3norm(L);
+            if (len < (real)1e-6) continue;
+            for (int x = 0; x < 3; x++) L[x] /= len;
+        } else {
+            type = 3;
+            real p0[3], s0[3], w[3];
+            closest_on_box(cb, B, hb, cc, p0);
+            v3sub(w, p0, cc);
+            real t = v3dot(w, a);
+            t = t < -hl ? -hl : (t > hl ? hl : t);
+            v3cpy(s0, cc); v3axpy(s0, t, a);
+            closest_on_box(cb, B, hb, s0, p0);
+            v3sub(L, s0, p0);
+            real len = v3norm(L);
+            if (len < (real)1e-9) continue;
+            for (int x = 0; x < 3; x++) L[x] /= len;
+        }
+        real t = v3dot(d, L), ca = v3dot(a, L);
+        real rc = hl * RFABS(ca) + rad * RSQRT(1 - ca * ca > 0 ? 1 - ca * ca : 0);
+        real sep = RFABS(t) - (box_proj(B, hb, L) + rc);
+        if (sep > margin) return 0;
+        real pen = type >= 2 ? (sep < 0 ? sep * EDGE_FUDGE : sep / EDGE_FUDGE) : sep;
+        if (pen > best) {
+            best = sep; btype = type; bk = k;
+            real sg = t < 0 ? (real)-1 : (real)1;
+            v3set(bn, sg * L[0], sg * L[1], sg * L[2]);
+        }
+    }
+    if (btype < 0) return 0;
+    real pts[12][3], sep[12];   /* candidate points ON THE CYLINDER side and their signed distances */
+    int m = 0;
+    const real* n = bn;
+    real can = v3dot(a, n);
+    if (btype == 0) {
+        real fp[3];
+        v3cpy(fp, cb);
+        v3axpy(fp, box_proj(B, hb, n), n);            /* a point of the supporting box face plane */
+        int j1 = (bk + 1) % 3, j2 = (bk + 2) % 3;
+        if (RFABS(can) >= (real)0.7) {
+            real sg = can > 0 ? (real)-1 : (real)1;    /* the cap that faces the box */
+            real pc[3];
+            v3cpy(pc, cc); v3axpy(pc, sg * hl, a);
+            for (int c = 0; c < 4; c++) {              /* rim points inside the face rectangle */
+                real p[3], w[3];
+                v3cpy(p, pc);
+                v3axpy(p, (c == 0 ? rad : (c == 1 ? -rad : 0)), u);
+                v3axpy(p, (c == 2 ? rad : (c == 3 ? -rad : 0)), v);
+                v3sub(w, p, cb);
+                if (RFABS(v3dot(w, B[j1])) <= hb[j1] && RFABS(v3dot(w, B[j2])) <= hb[j2]) {
+                    v3cpy(pts[m], p); v3sub(w, p, fp); sep[m] = v3dot(w, n); m++;
+                }
+            }
+            for (int c = 0; c < 4; c++) {              /* face corners inside the disc */
+                real q[3], w[3];
+                v3cpy(q, fp);
+                real nb = v3dot(n, B[bk]) > 0 ? (real)1 : (real)-1;
+                v3cpy(q, cb); v3axpy(q, nb * hb[bk], B[bk]);
+                v3axpy(q, ((c & 1) ? hb[j1] : -hb[j1]), B[j1]);
+                v3axpy(q, ((c & 2) ? hb[j2] : -hb[j2]), B[j2]);
+                v3sub(w, q, pc);
+                real wa = v3dot(w, a);
+                if (v3dot(w, w) - wa * wa <= rad * rad) {
+                    real t = -wa / can;                /* q + n t lies in the cap plane */
+                    v3cpy(pts[m], q); v3axpy(pts[m], t, n); sep[m] = t; m++;
+                }
+            }
+            if (m == 0) {                              /* partial overlap without a rim point / corner inside */
+                real q[3], w[3];
+                closest_on_box(cb, B, hb, pc, q);
+                v3sub(w, q, pc);
+                real wa = v3dot(w, a);
+                v3axpy(w, -wa, a);
+                real rho = v3norm(w);
+                real p[3];
+                v3cpy(p, pc);
+                if (rho > (real)1e-9) v3axpy(p, (rho < rad ? rho : rad) / rho, w);
+                v3sub(w, p, fp);
+                v3cpy(pts[m], p); sep[m] = v3dot(w, n); m++;
+            }
+        } else {
+            real mdir[3] = {n[0] - can * a[0], n[1] - can * a[1], n[2] - can * a[2]};
+            real ml = v3norm(mdir);
+            for (int x = 0; x < 3; x++) mdir[x] /= ml;
+            for (int e2 = 0; e2 < 2; e2++) {           /* both ends of the generator closest to the face */
+                real p[3], w[3];
+                v3cpy(p, cc);
+                v3axpy(p, -rad, mdir);
+                v3axpy(p, e2 == 0 ? hl : -hl, a);
+                v3sub(w, p, fp);
+                real s = v3dot(w, n);
+                if (s > margin) continue;
+                v3sub(w, p, cb);                       /* clamp onto the face rectangle along the in-plane axes */
+                real c1 = v3dot(w, B[j1]), c2 = v3dot(w, B[j2]);
+                real k1 = c1 < -hb[j1] ? -hb[j1] : (c1 > hb[j1] ? hb[j1] : c1);
+                real k2 = c2 < -hb[j2] ? -hb[j2] : (c2 > hb[j2] ? hb[j2] : c2);
+                v3axpy(p, k1 - c1, B[j1]);
+                v3axpy(p, k2 - c2, B[j2]);
+                v3cpy(pts[m], p); sep[m] = s; m++;
+            }
+        }
+    } else if (btype == 1) {
+        real pc[3];
+        v3cpy(pc, cc); v3axpy(pc, -hl, n);             /* cap facing the box (n = +-a) */
+        real smax = (real)-1e30, sv[8], q8[8][3];
+        for (int c = 0; c < 8; c++) {
+            v3cpy(q8[c], cb);
+            for (int k = 0; k < 3; k++) v3axpy(q8[c], ((c >> k) & 1) ? hb[k] : -hb[k], B[k]);
+            real w[3];
+            v3sub(w, q8[c], cb);
+            sv[c] = v3dot(w, n);
+            if (sv[c] > smax) smax = sv[c];
+        }
+        for (int c = 0; c < 8 && m < 8; c++) {
+            if (sv[c] < smax - (real)1e-3) continue;
+            real w[3];
+            v3sub(w, q8[c], pc);
+            real wa = v3dot(w, n);
+            real rho2 = v3dot(w, w) - wa * wa;
+            if (rho2 > rad * rad) continue;
+            v3cpy(pts[m], q8[c]); v3axpy(pts[m], -wa, n); sep[m] = -wa; m++;
+        }
+        if (m == 0) {
+            real q[3], w[3];
+            closest_on_box(cb, B, hb, pc, q);
+            v3sub(w, q, pc);
+            real wa = v3dot(w, n);
+            v3cpy(pts[m], q); v3axpy(pts[m], -wa, n); sep[m] = -wa; m++;
+        }
+    } else {
+        /* one point: closest points of the axis segment and the box, pushed to the lateral surface */
+        real p0[3], s0[3], w[3];
+        closest_on_box(cb, B, hb, cc, p0);
+        for (int it = 0; it < 4; it++) {
+            v3sub(w, p0, cc);
+            real t = v3dot(w, a);
+            t = t < -hl ? -hl : (t > hl ? hl : t);
+            v3cpy(s0, cc); v3axpy(s0, t, a);
+            closest_on_box(cb, B, hb, s0, p0);
+        }
+        v3cpy(pts[0], s0); v3axpy(pts[0], -rad, n);
+        sep[0] = best;
+        m = 1;
+    }
+    {   /* drop candidates beyond the speculative margin (keep the order) */
+        int k2 = 0;
+        for (int c = 0; c < m; c++)
+            if (sep[c] <= margin) { if (k2 != c) { v3cpy(pts[k2], pts[c]); sep[k2] = sep[c]; } k2++; }
+        m = k2;
+        if (m == 0) return 0;
+    }
+    int sel[4];
+    int ns = reduce4((const real (*)[3])pts, sep, m, sel);
+    for (int c = 0; c < ns; c++) {
+        int i = sel[c];
+        v3cpy(out[c].pa, pts[i]);
+        v3cpy(out[c].pb, pts[i]); v3axpy(out[c].pb, -sep[i], n);
+        v3cpy(out[c].n, n);
+        out[c].dist = sep[i];
+    }
+    return ns;
+}
+
+int pmgo_cyl_box(const double cc[3], const double Rc[9], double rad, double hl, const double cb[3], const double Rb[9],
+                 const double hb[3], double margin, double* out)
+{
+    real c1[3], c2[3], R1[9], R2[9], H[3];
+    for (int i = 0; i < 3; i++) { c1[i] = (real)cc[i]; c2[i] = (real)cb[i]; H[i] = (real)hb[i]; }
+    for (int i = 0; i < 9; i++) { R1[i] = (real)Rc[i]; R2[i] = (real)Rb[i]; }
+    CPoint cp[4];
+    int n = cyl_box(c1, R1, (real)rad, (real)hl, c2, R2, H, (real)margin, cp);
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) { out[10 * i + k] = cp[i].pa[k]; out[10 * i + 3 + k] = cp[i].pb[k]; out[10 * i + 6 + k] = cp[i].n[k]; }
+        out[10 * i + 9] = cp[i].dist;
+    }
+    return n;
+}
+
 int pmgo_box_box(const double ca[3], const double Ra[9], const double ha[3], const double cb[3], const double Rb[9],
                  const double hb[3], double margin, double* out)
 {
@@ -976,6 +1227,8 @@ struct pmgo_env {
     real ee_lo[3], ee_hi[3];
     real table_c[3], table_h[3], table_mu;
     real obj_z;
+    int obj_cyl;                 /* the single free object is the slide puck (cylinder) */
+    real obj_inertia[3], obj_half[3], obj_mu; /* principal inertia, half extents (cyl: r, r, h/2), friction */
     World* w;
     int nthreads;
     char err[256];
@@ -1004,12 +1257,12 @@ typedef struct {
 
 static void block_R(const Block* b, real* R) { quat_to_R(b->quat, R); }
 
-static void block_inv_inertia_apply(const Block* b, const real* t, real* out)
+static void block_inv_inertia_apply(const pmgo_env* e, const Block* b, const real* t, real* out)
 {
     real R[9], l[3];
     block_R(b, R);
     m3tv(l, R, t);
-    for (int a = 0; a < 3; a++) l[a] /= (real)BLOCK_INERTIA[a];
+    for (int a = 0; a < 3; a++) l[a] /= e->obj_inertia[a];
     m3v(out, R, l);
 }
 
@@ -1017,7 +1270,6 @@ static void block_inv_inertia_apply(const Block* b, const real* t, real* out)
 static void row_setup(const pmgo_env* e, const World* w, const Kin* k, const AbaCache* ac, Row* r, int a, int b,
                       const real* pa, const real* pb, const real* n, real* rel_vel_out)
 {
-    (void)e;
     memset(r, 0, sizeof(*r));
     r->blk[0] = r->blk[1] = -1;
     real denom = 0, rel = 0;
@@ -1040,7 +1292,7 @@ static void row_setup(const pmgo_env* e, const World* w, const Kin* k, const Aba
             for (int c = 0; c < 3; c++) { r->Jl[s][c] = sg * n[c]; r->Ja[s][c] = sg * rxn[c]; }
             r->blk[s] = id;
             for (int c = 0; c < 3; c++) r->dl[s][c] = r->Jl[s][c] / (real)PMG_BLOCK_MASS;
-            block_inv_inertia_apply(bl, r->Ja[s], r->da[s]);
+            block_inv_inertia_apply(e, bl, r->Ja[s], r->da[s]);
             denom += v3dot(r->Jl[s], r->dl[s]) + v3dot(r->Ja[s], r->da[s]);
             rel += v3dot(r->Jl[s], bl->vel) + v3dot(r->Ja[s], bl->omg);
         }
@@ -1063,13 +1315,30 @@ static void robot_box_pose(const Kin* k, int L, real* c, real* R)
     memcpy(R, k->R[L], 9 * sizeof(real));
 }
 
+/* object b against a box B (table / finger): box-box, or cylinder-box for the slide puck.
+ * obj_is_A: the object is body A of the pair (normal from B to A); otherwise the box is A. */
+static int obj_vs_box(const pmgo_env* e, const World* w, const real (*Rb)[9], int b, int obj_is_A, const real* bc,
+                      const real* bR, const real* bh, CPoint* cp)
+{
+    if (!e->obj_cyl)
+        return obj_is_A ? box_box(w->blk[b].pos, Rb[b], e->obj_half, bc, bR, bh, CONTACT_MARGIN, cp)
+                        : box_box(bc, bR, bh, w->blk[b].pos, Rb[b], e->obj_half, CONTACT_MARGIN, cp);
+    int n = cyl_box(w->blk[b].pos, Rb[b], e->obj_half[0], e->obj_half[2], bc, bR, bh, CONTACT_MARGIN, cp);
+    if (!obj_is_A)
+        for (int c = 0; c < n; c++) { /* cyl_box reports the cylinder as A: swap roles */
+            real t[3];
+            v3cpy(t, cp[c].pa); v3cpy(cp[c].pa, cp[c].pb); v3cpy(cp[c].pb, t);
+            v3set(cp[c].n, -cp[c].n[0], -cp[c].n[1], -cp[c].n[2]);
+        }
+    return n;
+}
+
 static int collide(const pmgo_env* e, const World* w, const Kin* k, Contact* out)
 {
     int nc = 0;
     CPoint cp[4];
     real I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     real fh[3] = {(real)FINGER_HALF[0], (real)FINGER_HALF[1], (real)FINGER_HALF[2]};
-    real bh[3] = {(real)BLOCK_HALF[0], (real)BLOCK_HALF[1], (real)BLOCK_HALF[2]};
     real Rb[NBMAX][9];
     for (int b = 0; b < e->nb; b++) block_R(&w->blk[b], Rb[b]);
 #define EMIT(A, B, MU)                                                                  \
@@ -1078,10 +1347,10 @@ static int collide(const pmgo_env* e, const World* w, const Kin* k, Contact* out
         o->a = (A); o->b = (B); o->mu = (MU); o->dist = cp[c_].dist;                    \
         v3cpy(o->pa, cp[c_].pa); v3cpy(o->pb, cp[c_].pb); v3cpy(o->n, cp[c_].n);        \
     }
-    /* block (A) x table (B) */
+    /* object (A) x table (B) */
     for (int b = 0; b < e->nb; b++) {
-        int n_ = box_box(w->blk[b].pos, Rb[b], bh, e->table_c, I3, e->table_h, CONTACT_MARGIN, cp);
-        EMIT(b, BODY_STATIC, (real)PMG_BLOCK_FRICTION * e->table_mu)
+        int n_ = obj_vs_box(e, w, (const real (*)[9])Rb, b, 1, e->table_c, I3, e->table_h, cp);
+        EMIT(b, BODY_STATIC, e->obj_mu * e->table_mu)
     }
     /* block x block */
     for (int b = 0; b < e->nb; b++)
@@ -1089,10 +1358,10 @@ static int collide(const pmgo_env* e, const World* w, const Kin* k, Contact* out
             real dd[3];
             v3sub(dd, w->blk[b].pos, w->blk[c].pos);
             if (v3dot(dd, dd) > (real)(0.06 * 0.06)) continue; /* bounding spheres: 2*sqrt(3)*0.015+margin < 0.06 */
-            int n_ = box_box(w->blk[b].pos, Rb[b], bh, w->blk[c].pos, Rb[c], bh, CONTACT_MARGIN, cp);
-            EMIT(b, c, (real)(PMG_BLOCK_FRICTION * PMG_BLOCK_FRICTION))
+            int n_ = box_box(w->blk[b].pos, Rb[b], e->obj_half, w->blk[c].pos, Rb[c], e->obj_half, CONTACT_MARGIN, cp);
+            EMIT(b, c, e->obj_mu * e->obj_mu)
         }
-    /* fingers (A) x blocks (B), fingers x table */
+    /* fingers (A) x objects (B), fingers x table */
     static const int FL[2] = {PMG_BL_FINGER1, PMG_BL_FINGER2};
     for (int f = 0; f < 2; f++) {
         real fc[3], fR[9];
@@ -1100,15 +1369,26 @@ static int collide(const pmgo_env* e, const World* w, const Kin* k, Contact* out
         for (int b = 0; b < e->nb; b++) {
             real dd[3];
             v3sub(dd, fc, w->blk[b].pos);
-            if (v3dot(dd, dd) > (real)(0.075 * 0.075)) continue; /* 0.0431 + 0.026 + margin */
-            int n_ = box_box(fc, fR, fh, w->blk[b].pos, Rb[b], bh, CONTACT_MARGIN, cp);
-            EMIT(BODY_ROBOT(FL[f]), b, (real)(PMG_FINGER_FRICTION * PMG_BLOCK_FRICTION))
+            if (v3dot(dd, dd) > (real)(0.08 * 0.08)) continue; /* finger 0.0431 + object <= 0.0317 + margin */
+            int n_ = obj_vs_box(e, w, (const real (*)[9])Rb, b, 0, fc, fR, fh, cp);
+            EMIT(BODY_ROBOT(FL[f]), b, (real)PMG_FINGER_FRICTION * e->obj_mu)
         }
         if (fc[2] - (real)0.0431 < e->table_c[2] + e->table_h[2] + CONTACT_MARGIN) {
             int n_ = box_box(fc, fR, fh, e->table_c, I3, e->table_h, CONTACT_MARGIN, cp);
             EMIT(BODY_ROBOT(FL[f]), BODY_STATIC, (real)PMG_FINGER_FRICTION * e->table_mu)
         }
     }
+    /* gripper base cylinder (A, on link 7) x blocks (B); the puck never reaches it (tip z >= 0.175) */
+    if (!e->obj_cyl)
+        for (int b = 0; b < e->nb; b++) {
+            const real* gc = k->p[PMG_BL_GBASE];
+            real dd[3];
+            v3sub(dd, gc, w->blk[b].pos);
+            if (v3dot(dd, dd) > (real)(0.085 * 0.085)) continue; /* 0.0539 + 0.026 + margin */
+            int n_ = cyl_box(gc, k->R[PMG_BL_GBASE], (real)PMG_GBASE_RADIUS, (real)PMG_GBASE_HALFLEN, w->blk[b].pos, Rb[b],
+                             e->obj_half, CONTACT_MARGIN, cp);
+            EMIT(BODY_ROBOT(PMG_BL_GBASE), b, GBASE_FRICTION * e->obj_mu)
+        }
 #undef EMIT
     return nc;
 }
@@ -1168,9 +1448,9 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
         real R[9], wl[3], Iw[3], gy[3], tq[3], al[3];
         block_R(bl, R);
         m3tv(wl, R, bl->omg);
-        for (int a = 0; a < 3; a++) Iw[a] = (real)BLOCK_INERTIA[a] * wl[a];
+        for (int a = 0; a < 3; a++) Iw[a] = e->obj_inertia[a] * wl[a];
         v3cross(gy, wl, Iw);
-        for (int a = 0; a < 3; a++) tq[a] = (-Iw[a] * ka - gy[a]) / (real)BLOCK_INERTIA[a];
+        for (int a = 0; a < 3; a++) tq[a] = (-Iw[a] * ka - gy[a]) / e->obj_inertia[a];
         m3v(al, R, tq);
         for (int a = 0; a < 3; a++) {
             bl->vel[a] += dt * (-bl->vel[a] * kl + (a == 2 ? -GRAVITY : 0));
@@ -1335,6 +1615,9 @@ static void env_constants(pmgo_env* e)
     for (int a = 0; a < 3; a++) e->table_h[a] = (real)TABLE_HALF[a];
     e->table_mu = (real)PMG_TABLE_FRICTION;
     e->obj_z = (real)0.175;
+    e->obj_cyl = 0;
+    e->obj_mu = (real)PMG_BLOCK_FRICTION;
+    for (int a = 0; a < 3; a++) { e->obj_inertia[a] = (real)BLOCK_INERTIA[a]; e->obj_half[a] = (real)BLOCK_HALF[a]; }
     if (t == PMG_TASK_SLIDE) { /* kuka_single_step_base_env.py:53-56,66-69 */
         e->tgt_lo[0] -= (real)0.4; e->tgt_hi[0] -= (real)0.4;
         e->table_c[0] = (real)-0.70;
@@ -1342,6 +1625,10 @@ static void env_constants(pmgo_env* e)
         for (int a = 0; a < 3; a++) e->table_h[a] = (real)LT[a];
         e->table_mu = (real)PMG_LONG_TABLE_FRICTION;
         e->obj_z = (real)0.170;
+        static const double PI[3] = PMG_PUCK_INERTIA, PH[3] = PMG_PUCK_HALF;   /* cylinder_bulk.urdf */
+        e->obj_cyl = 1;
+        e->obj_mu = (real)PMG_PUCK_FRICTION;
+        for (int a = 0; a < 3; a++) { e->obj_inertia[a] = (real)PI[a]; e->obj_half[a] = (real)PH[a]; }
     }
 }
 
@@ -1591,7 +1878,7 @@ int pmgo_create(const pmg_config* cfg, pmgo_env** out)
     }
     pmgo_env* e = (pmgo_env*)calloc(1, sizeof(pmgo_env));
     e->cfg = *cfg;
-    if (fill_dims(cfg, &e->dims) != 0 || cfg->task == PMG_TASK_SLIDE) {
+    if (fill_dims(cfg, &e->dims) != 0) {
         snprintf(g_create_err, sizeof(g_create_err), "pmgo_create: unsupported task %d / num_block %d", cfg->task, cfg->num_block);
         free(e);
         return PMG_E_INVALID;

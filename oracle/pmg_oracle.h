@@ -57,6 +57,9 @@ void pmgo_fdyn(const double q[9], const double qd[9], const double tau[9], doubl
 /* box-box narrowphase probe: returns n contacts (<=4); out[n][10] = pa3 pb3 n3 dist */
 int pmgo_box_box(const double ca[3], const double Ra[9], const double ha[3], const double cb[3],
                  const double Rb[9], const double hb[3], double margin, double* out);
+/* cylinder (A) x box (B) narrowphase probe, same output convention */
+int pmgo_cyl_box(const double cc[3], const double Rc[9], double rad, double hl, const double cb[3], const double Rb[9],
+                 const double hb[3], double margin, double* out);
 /* gym.utils.seeding.np_random(seed) + RandomState draws (tests/golden/rng.json) */
 void pmgo_rng_probe(uint64_t seed, int n_double, double* out_double, int shuffle_n, int32_t* out_perm);
 

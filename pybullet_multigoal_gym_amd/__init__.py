@@ -13,7 +13,7 @@ _TASKS = ['push', 'reach', 'slide', 'pick_and_place',
           'block_stack', 'block_rearrange', 'chest_pick_and_place', 'chest_push',
           'primitive_push_assemble', 'primitive_push_reach', 'insertion']
 _GRIPPERS = ['robotiq85', 'parallel_jaw']
-_ACCELERATED = ['reach', 'push', 'pick_and_place', 'block_stack']
+_ACCELERATED = ['reach', 'push', 'slide', 'pick_and_place', 'block_stack']
 
 
 def make_env(task='reach', gripper='parallel_jaw', num_block=5, render=False, binary_reward=True,

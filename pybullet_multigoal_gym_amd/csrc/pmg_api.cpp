@@ -139,13 +139,13 @@ int fill_dims(const pmg_config* c, pmg_dims* d, int* nb_out)
     d->num_envs = c->num_envs;
     switch (c->task) {
     case PMG_TASK_REACH: d->action_dim = jo ? 7 : 3; d->observation_dim = 3 + jo; d->policy_state_dim = 3 + jo; d->goal_dim = 3; break;
-    case PMG_TASK_PUSH: d->action_dim = jo ? 7 : 3; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
+    case PMG_TASK_PUSH: case PMG_TASK_SLIDE: d->action_dim = jo ? 7 : 3; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
     case PMG_TASK_PICK_AND_PLACE: d->action_dim = jo ? 8 : 4; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
     case PMG_TASK_BLOCK_STACK:
         if (c->num_block < 1 || c->num_block > 5) return -1;
         d->action_dim = jo ? 8 : 4; d->observation_dim = 8 + 16 * c->num_block + jo;
         d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; break;
-    default: return -1; /* slide (cylinder puck) is not built yet */
+    default: return -1;
     }
     int nb = c->task == PMG_TASK_REACH ? 0 : (c->task == PMG_TASK_BLOCK_STACK ? c->num_block : 1);
     *nb_out = nb;
@@ -170,14 +170,15 @@ void fill_params(pmg_env* e)
     P.gdim = e->dims.goal_dim; P.packed = e->dims.packed_dim;
     P.thr = c.distance_threshold;
     bool on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE);
-    double range = 0.15;
+    double range = 0.15, trange = 0.15;
+    if (t == PMG_TASK_SLIDE) { range = 0.1; trange = 0.2; } /* kuka_single_step_base_env.py:66-69 */
     P.tip_init[0] = -0.52; P.tip_init[1] = 0.0; P.tip_init[2] = 0.25;
     if (on_table) P.tip_init[2] = 0.175 + 0.001;
     const double hi[3] = {-0.37, 0.20, 0.55}, lo[3] = {-0.67, -0.20, 0.175};
     for (int a = 0; a < 3; a++) {
         P.ee_hi[a] = (float)hi[a]; P.ee_lo[a] = (float)lo[a];
         P.obj_lo[a] = P.tip_init[a] - range; P.obj_hi[a] = P.tip_init[a] + range;
-        P.tgt_lo[a] = P.tip_init[a] - range; P.tgt_hi[a] = P.tip_init[a] + range;
+        P.tgt_lo[a] = P.tip_init[a] - trange; P.tgt_hi[a] = P.tip_init[a] + trange;
     }
     P.obj_lo[0] += 0.03; P.obj_hi[0] -= 0.03;
     P.tgt_lo[0] += 0.03; P.tgt_hi[0] -= 0.03;
@@ -187,6 +188,20 @@ void fill_params(pmg_env* e)
     P.table_c[0] = -0.52f; P.table_c[1] = 0.f; P.table_c[2] = 0.08f;
     for (int a = 0; a < 3; a++) P.table_h[a] = th[a];
     P.table_mu = (float)PMG_TABLE_FRICTION;
+    P.obj.cyl = 0;
+    P.obj.mu = (float)PMG_BLOCK_FRICTION;
+    for (int a = 0; a < 3; a++) { P.obj.half[a] = pmg::BLOCK_HALF; P.obj.inv_inertia[a] = 1.f / pmg::BLOCK_INERTIA; }
+    if (t == PMG_TASK_SLIDE) { /* long table + puck: kuka_single_step_base_env.py:53-56, cylinder_bulk.urdf, table_long.urdf */
+        const float lt[3] = PMG_LONG_TABLE_HALF, ph[3] = PMG_PUCK_HALF;
+        const double pi[3] = PMG_PUCK_INERTIA;
+        P.tgt_lo[0] -= 0.4; P.tgt_hi[0] -= 0.4;
+        P.table_c[0] = -0.70f;
+        for (int a = 0; a < 3; a++) { P.table_h[a] = lt[a]; P.obj.half[a] = ph[a]; P.obj.inv_inertia[a] = (float)(1.0 / pi[a]); }
+        P.table_mu = (float)PMG_LONG_TABLE_FRICTION;
+        P.obj_z = 0.170;
+        P.obj.cyl = 1;
+        P.obj.mu = (float)PMG_PUCK_FRICTION;
+    }
 }
 
 int upload_seeds(pmg_env* e)

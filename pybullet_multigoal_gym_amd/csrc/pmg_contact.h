@@ -373,6 +373,238 @@ __device__ inline int box_box_fast(const float* ca, const float* Ra, const float
     return ns;
 }
 
+/* ---------------------------------------------------------------- */
+/* cylinder (A) x box (B): gripper-base x block and the slide puck x table / finger.  Finite
+ * separating-axis search (3 box face normals, cylinder axis, 3 axis x edge, 1 closest feature) and
+ * feature clipping to <= 4 points, as oracle/pmg_oracle.c cyl_box.  n from the box to the cylinder.
+ * W: per-lane LDS workspace (>= 84 floats): pts[12][3] sep[12] q8[8][3] sv[8] sel[4].           */
+__device__ __forceinline__ float box_proj(const float (*B)[3], const float* hb, const float* L)
+{
+    return hb[0] * fabsf(dot3(B[0], L)) + hb[1] * fabsf(dot3(B[1], L)) + hb[2] * fabsf(dot3(B[2], L));
+}
+__device__ __forceinline__ void closest_on_box(const float* cb, const float (*B)[3], const float* hb, const float* p, float* q)
+{
+    float d[3] = {p[0] - cb[0], p[1] - cb[1], p[2] - cb[2]};
+    q[0] = cb[0]; q[1] = cb[1]; q[2] = cb[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float t = fminf(fmaxf(dot3(d, B[k]), -hb[k]), hb[k]);
+        q[0] += t * B[k][0]; q[1] += t * B[k][1]; q[2] += t * B[k][2];
+    }
+}
+__device__ inline int reduce4(const float (*pts)[3], const float* sep, int m, int* sel)
+{
+    if (m <= 4) { for (int c = 0; c < m; c++) sel[c] = c; return m; }
+    int i0 = 0;
+    for (int c = 1; c < m; c++) if (sep[c] < sep[i0]) i0 = c;
+    int i1 = -1; float bd = -1.f;
+    for (int c = 0; c < m; c++) {
+        if (c == i0) continue;
+        float d[3] = {pts[c][0] - pts[i0][0], pts[c][1] - pts[i0][1], pts[c][2] - pts[i0][2]};
+        float dd = dot3(d, d);
+        if (dd > bd) { bd = dd; i1 = c; }
+    }
+    int i2 = -1, i3 = -1; float amax = 0.f, amin = 0.f;
+    float e[3] = {pts[i1][0] - pts[i0][0], pts[i1][1] - pts[i0][1], pts[i1][2] - pts[i0][2]};
+    float ref[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < m; c++) {
+        if (c == i0 || c == i1) continue;
+        float f[3] = {pts[c][0] - pts[i0][0], pts[c][1] - pts[i0][1], pts[c][2] - pts[i0][2]}, x[3];
+        cross3(e, f, x);
+        if (dot3(ref, ref) == 0.f && dot3(x, x) > 0.f) { ref[0] = x[0]; ref[1] = x[1]; ref[2] = x[2]; }
+        float ar = dot3(x, ref);
+        if (ar > amax) { amax = ar; i2 = c; }
+        if (ar < amin) { amin = ar; i3 = c; }
+    }
+    int ns = 0;
+    sel[ns++] = i0; sel[ns++] = i1;
+    if (i2 >= 0) sel[ns++] = i2;
+    if (i3 >= 0) sel[ns++] = i3;
+    return ns;
+}
+__device__ __noinline__ inline int cyl_box(const float* cc, const float* Rc, float rad, float hl, const float* cb, const float* Rb,
+                              const float* hb_in, float margin, float* out, float* W)
+{
+    float a[3] = {Rc[2], Rc[5], Rc[8]}, u[3] = {Rc[0], Rc[3], Rc[6]}, v[3] = {Rc[1], Rc[4], Rc[7]};
+    float B[3][3], hb[3] = {hb_in[0], hb_in[1], hb_in[2]};
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int x = 0; x < 3; x++) B[k][x] = Rb[3 * x + k];
+    float d[3] = {cc[0] - cb[0], cc[1] - cb[1], cc[2] - cb[2]};
+    float best = -1e30f, n[3] = {0.f, 0.f, 0.f};
+    int btype = -1, bk = 0;
+#pragma unroll
+    for (int pass = 0; pass < 8; pass++) {
+        float L[3];
+        int type, k = 0;
+        bool valid = true;
+        if (pass < 3) { type = 0; k = pass; L[0] = B[pass][0]; L[1] = B[pass][1]; L[2] = B[pass][2]; }
+        else if (pass == 3) { type = 1; L[0] = a[0]; L[1] = a[1]; L[2] = a[2]; }
+        else if (pass < 7) {
+            type = 2; k = pass - 4;
+            cross3(a, B[pass - 4], L);
+            float len = sqrtf(dot3(L, L));
+            valid = !(len < 1e-6f);
+            float il = valid ? 1.f / len : 0.f;
+            L[0] *= il; L[1] *= il; L[2] *= il;
+        } else {
+            type = 3;
+            float p0[3], s0[3];
+            closest_on_box(cb, B, hb, cc, p0);
+            float w[3] = {p0[0] - cc[0], p0[1] - cc[1], p0[2] - cc[2]};
+            float t = fminf(fmaxf(dot3(w, a), -hl), hl);
+            s0[0] = cc[0] + t * a[0]; s0[1] = cc[1] + t * a[1]; s0[2] = cc[2] + t * a[2];
+            closest_on_box(cb, B, hb, s0, p0);
+            L[0] = s0[0] - p0[0]; L[1] = s0[1] - p0[1]; L[2] = s0[2] - p0[2];
+            float len = sqrtf(dot3(L, L));
+            valid = !(len < 1e-9f);
+            float il = valid ? 1.f / len : 0.f;
+            L[0] *= il; L[1] *= il; L[2] *= il;
+        }
+        if (!valid) continue;
+        float t = dot3(d, L), ca = dot3(a, L);
+        float rc = hl * fabsf(ca) + rad * sqrtf(fmaxf(1.f - ca * ca, 0.f));
+        float sp = fabsf(t) - (box_proj(B, hb, L) + rc);
+        if (sp > margin) return 0;
+        float pen = type >= 2 ? (sp < 0.f ? sp * EDGE_FUDGE : sp / EDGE_FUDGE) : sp;
+        if (pen > best) {
+            best = sp; btype = type; bk = k;
+            float sg = t < 0.f ? -1.f : 1.f;
+            n[0] = sg * L[0]; n[1] = sg * L[1]; n[2] = sg * L[2];
+        }
+    }
+    if (btype < 0) return 0;
+    float (*pts)[3] = (float (*)[3])(W + 0);
+    float* sep = W + 36;
+    int m = 0;
+    float can = dot3(a, n);
+    if (btype == 0) {
+        float bp = box_proj(B, hb, n);
+        float fp[3] = {cb[0] + bp * n[0], cb[1] + bp * n[1], cb[2] + bp * n[2]};
+        const float* Bk = bk == 0 ? B[0] : (bk == 1 ? B[1] : B[2]);
+        const float* B1 = bk == 0 ? B[1] : (bk == 1 ? B[2] : B[0]);
+        const float* B2 = bk == 0 ? B[2] : (bk == 1 ? B[0] : B[1]);
+        float hk = bk == 0 ? hb[0] : (bk == 1 ? hb[1] : hb[2]);
+        float h1 = bk == 0 ? hb[1] : (bk == 1 ? hb[2] : hb[0]);
+        float h2 = bk == 0 ? hb[2] : (bk == 1 ? hb[0] : hb[1]);
+        if (fabsf(can) >= 0.7f) {
+            float sg = can > 0.f ? -1.f : 1.f;
+            float pc[3] = {cc[0] + sg * hl * a[0], cc[1] + sg * hl * a[1], cc[2] + sg * hl * a[2]};
+            for (int c = 0; c < 4; c++) {
+                float ku = c == 0 ? rad : (c == 1 ? -rad : 0.f), kv = c == 2 ? rad : (c == 3 ? -rad : 0.f);
+                float p[3] = {pc[0] + ku * u[0] + kv * v[0], pc[1] + ku * u[1] + kv * v[1], pc[2] + ku * u[2] + kv * v[2]};
+                float w[3] = {p[0] - cb[0], p[1] - cb[1], p[2] - cb[2]};
+                if (fabsf(dot3(w, B1)) <= h1 && fabsf(dot3(w, B2)) <= h2) {
+                    pts[m][0] = p[0]; pts[m][1] = p[1]; pts[m][2] = p[2];
+                    float w2[3] = {p[0] - fp[0], p[1] - fp[1], p[2] - fp[2]};
+                    sep[m] = dot3(w2, n); m++;
+                }
+            }
+            float nb = dot3(n, Bk) > 0.f ? 1.f : -1.f;
+            for (int c = 0; c < 4; c++) {
+                float s1 = (c & 1) ? h1 : -h1, s2 = (c & 2) ? h2 : -h2;
+                float q[3];
+                for (int x = 0; x < 3; x++) q[x] = cb[x] + nb * hk * Bk[x] + s1 * B1[x] + s2 * B2[x];
+                float w[3] = {q[0] - pc[0], q[1] - pc[1], q[2] - pc[2]};
+                float wa = dot3(w, a);
+                if (dot3(w, w) - wa * wa <= rad * rad) {
+                    float t = -wa / can;
+                    pts[m][0] = q[0] + t * n[0]; pts[m][1] = q[1] + t * n[1]; pts[m][2] = q[2] + t * n[2];
+                    sep[m] = t; m++;
+                }
+            }
+            if (m == 0) {
+                float q[3];
+                closest_on_box(cb, B, hb, pc, q);
+                float w[3] = {q[0] - pc[0], q[1] - pc[1], q[2] - pc[2]};
+                float wa = dot3(w, a);
+                w[0] -= wa * a[0]; w[1] -= wa * a[1]; w[2] -= wa * a[2];
+                float rho = sqrtf(dot3(w, w));
+                float sc = rho > 1e-9f ? fminf(rho, rad) / rho : 0.f;
+                float p[3] = {pc[0] + sc * w[0], pc[1] + sc * w[1], pc[2] + sc * w[2]};
+                float w2[3] = {p[0] - fp[0], p[1] - fp[1], p[2] - fp[2]};
+                pts[m][0] = p[0]; pts[m][1] = p[1]; pts[m][2] = p[2]; sep[m] = dot3(w2, n); m++;
+            }
+        } else {
+            float md[3] = {n[0] - can * a[0], n[1] - can * a[1], n[2] - can * a[2]};
+            float ml = 1.f / sqrtf(dot3(md, md));
+            md[0] *= ml; md[1] *= ml; md[2] *= ml;
+            for (int e2 = 0; e2 < 2; e2++) {
+                float he = e2 == 0 ? hl : -hl;
+                float p[3] = {cc[0] - rad * md[0] + he * a[0], cc[1] - rad * md[1] + he * a[1], cc[2] - rad * md[2] + he * a[2]};
+                float w[3] = {p[0] - fp[0], p[1] - fp[1], p[2] - fp[2]};
+                float sd = dot3(w, n);
+                if (sd > margin) continue;
+                float w2[3] = {p[0] - cb[0], p[1] - cb[1], p[2] - cb[2]};
+                float c1 = dot3(w2, B1), c2 = dot3(w2, B2);
+                float k1 = fminf(fmaxf(c1, -h1), h1), k2 = fminf(fmaxf(c2, -h2), h2);
+                for (int x = 0; x < 3; x++) p[x] += (k1 - c1) * B1[x] + (k2 - c2) * B2[x];
+                pts[m][0] = p[0]; pts[m][1] = p[1]; pts[m][2] = p[2]; sep[m] = sd; m++;
+            }
+        }
+    } else if (btype == 1) {
+        float pc[3] = {cc[0] - hl * n[0], cc[1] - hl * n[1], cc[2] - hl * n[2]};
+        float (*q8)[3] = (float (*)[3])(W + 48);
+        float* sv = W + 72;
+        float smax = -1e30f;
+        for (int c = 0; c < 8; c++) {
+            for (int x = 0; x < 3; x++)
+                q8[c][x] = cb[x] + ((c & 1) ? hb[0] : -hb[0]) * B[0][x] + ((c & 2) ? hb[1] : -hb[1]) * B[1][x] + ((c & 4) ? hb[2] : -hb[2]) * B[2][x];
+            float w[3] = {q8[c][0] - cb[0], q8[c][1] - cb[1], q8[c][2] - cb[2]};
+            sv[c] = dot3(w, n);
+            smax = fmaxf(smax, sv[c]);
+        }
+        for (int c = 0; c < 8 && m < 8; c++) {
+            if (sv[c] < smax - 1e-3f) continue;
+            float w[3] = {q8[c][0] - pc[0], q8[c][1] - pc[1], q8[c][2] - pc[2]};
+            float wa = dot3(w, n);
+            if (dot3(w, w) - wa * wa > rad * rad) continue;
+            pts[m][0] = q8[c][0] - wa * n[0]; pts[m][1] = q8[c][1] - wa * n[1]; pts[m][2] = q8[c][2] - wa * n[2];
+            sep[m] = -wa; m++;
+        }
+        if (m == 0) {
+            float q[3];
+            closest_on_box(cb, B, hb, pc, q);
+            float w[3] = {q[0] - pc[0], q[1] - pc[1], q[2] - pc[2]};
+            float wa = dot3(w, n);
+            pts[m][0] = q[0] - wa * n[0]; pts[m][1] = q[1] - wa * n[1]; pts[m][2] = q[2] - wa * n[2];
+            sep[m] = -wa; m++;
+        }
+    } else {
+        float p0[3], s0[3] = {cc[0], cc[1], cc[2]};
+        closest_on_box(cb, B, hb, cc, p0);
+        for (int it = 0; it < 4; it++) {
+            float w[3] = {p0[0] - cc[0], p0[1] - cc[1], p0[2] - cc[2]};
+            float t = fminf(fmaxf(dot3(w, a), -hl), hl);
+            s0[0] = cc[0] + t * a[0]; s0[1] = cc[1] + t * a[1]; s0[2] = cc[2] + t * a[2];
+            closest_on_box(cb, B, hb, s0, p0);
+        }
+        pts[0][0] = s0[0] - rad * n[0]; pts[0][1] = s0[1] - rad * n[1]; pts[0][2] = s0[2] - rad * n[2];
+        sep[0] = best;
+        m = 1;
+    }
+    {
+        int k2 = 0;
+        for (int c = 0; c < m; c++)
+            if (sep[c] <= margin) {
+                if (k2 != c) { pts[k2][0] = pts[c][0]; pts[k2][1] = pts[c][1]; pts[k2][2] = pts[c][2]; sep[k2] = sep[c]; }
+                k2++;
+            }
+        m = k2;
+        if (m == 0) return 0;
+    }
+    int* sel = (int*)(W + 80);
+    int ns = reduce4((const float (*)[3])pts, sep, m, sel);
+    for (int c = 0; c < ns; c++) {
+        int i = sel[c];
+        float* o = out + CP * c;
+        for (int x = 0; x < 3; x++) { o[x] = pts[i][x]; o[3 + x] = pts[i][x] - sep[i] * n[x]; o[6 + x] = n[x]; }
+        o[9] = sep[i];
+    }
+    return ns;
+}
+
 /* [BULLET-PRIOR] btPlaneSpace1 */
 __device__ __forceinline__ void plane_space(const float* n, float* p, float* q)
 {
@@ -403,15 +635,16 @@ __device__ __forceinline__ void quat_to_R(const float* q, float* R)
 
 /* body ids in contacts */
 constexpr int BODY_STATIC = -1;
-constexpr int BODY_FINGER1 = 5, BODY_FINGER2 = 6; /* blocks are 0..4 */
+constexpr int BODY_FINGER1 = 5, BODY_FINGER2 = 6, BODY_GBASE = 7; /* blocks are 0..4; 5..7 ride on the robot */
 
 /* per-env LDS of the contact path */
 template <int NB, int MAXC>
 struct ContactLds {
-    static constexpr int NPAIR = NB + NB * (NB - 1) / 2 + 2 * (NB + 1);
+    static constexpr int NPAIR = NB + NB * (NB - 1) / 2 + 2 * (NB + 1) + NB;
     float blk[NB > 0 ? NB : 1][BLOCK_DIM];    /* pos3 quat4 vel3 omg3 (persistent over the substeps) */
     float blkR[NB > 0 ? NB : 1][9];
     float fing[2][12];                         /* finger box centre + rotation */
+    float gbase[12];                           /* gripper-base cylinder centre + rotation (link 7) */
     float S[NJ][6];
     float qd[NJ];
     float minv[NJ][NJ];
@@ -433,7 +666,7 @@ struct ContactLds {
 template <int NB>
 __device__ __forceinline__ void decode_pair(int i, int nb, int& a, int& b)
 {
-    /* order: block x table | block x block (b < c) | finger f: blocks..., table */
+    /* order: object x table | block x block (b < c) | finger f: objects..., table | gripper base x blocks */
     if (i < nb) { a = i; b = BODY_STATIC; return; }
     i -= nb;
     int nbb = nb * (nb - 1) / 2;
@@ -446,9 +679,15 @@ __device__ __forceinline__ void decode_pair(int i, int nb, int& a, int& b)
             }
     }
     i -= nbb;
-    int f = i / (nb + 1), r = i % (nb + 1);
-    a = f == 0 ? BODY_FINGER1 : BODY_FINGER2;
-    b = r < nb ? r : BODY_STATIC;
+    if (i < 2 * (nb + 1)) {
+        int f = i / (nb + 1), r = i % (nb + 1);
+        a = f == 0 ? BODY_FINGER1 : BODY_FINGER2;
+        b = r < nb ? r : BODY_STATIC;
+        return;
+    }
+    i -= 2 * (nb + 1);
+    a = BODY_GBASE; /* gripper-base cylinder x block i */
+    b = i;
 }
 
 /* lowest z of the oriented finger box (exact AABB extent): a separating-axis bound for finger x table */
@@ -459,34 +698,61 @@ __device__ __forceinline__ float finger_zmin(const float* c, const float* R)
 }
 
 /* collision detection for every candidate pair of this env; fills L.con / L.ncon (uniform) */
+/* per-task properties of the free object(s): the 3 cm blocks, or the slide puck (cylinder_bulk.urdf) */
+struct ObjParams {
+    int cyl;              /* 1: cylinder (half = r, r, h/2) */
+    float half[3];
+    float inv_inertia[3]; /* principal, body frame */
+    float mu;
+};
+
 template <int NB, int MAXC>
-__device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const float* table_c, const float* table_h, float table_mu)
+__device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const float* table_c, const float* table_h, float table_mu,
+                                       const ObjParams& ob)
 {
-    using LT = ContactLds<NB, MAXC>;
     int l = wv::lane();
-    int npair = nb + nb * (nb - 1) / 2 + 2 * (nb + 1);
+    int npair = nb + nb * (nb - 1) / 2 + 2 * (nb + 1) + (ob.cyl ? 0 : nb);
     const float I3[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     const float fh[3] = PMG_FINGER_HALF;
-    const float bh[3] = {BLOCK_HALF, BLOCK_HALF, BLOCK_HALF};
     for (int i = l; i < npair; i += 64) {
         int a, b;
         decode_pair<NB>(i, nb, a, b);
-        const float *ca, *Ra, *ha, *cb, *Rb, *hb;
         float tc[3] = {table_c[0], table_c[1], table_c[2]}, th[3] = {table_h[0], table_h[1], table_h[2]};
-        if (a >= BODY_FINGER1) { ca = L.fing[a - BODY_FINGER1]; Ra = L.fing[a - BODY_FINGER1] + 3; ha = fh; }
-        else { ca = L.blk[a]; Ra = L.blkR[a]; ha = bh; }
-        bool cull = false;
-        if (b == BODY_STATIC) {
-            cb = tc; Rb = I3; hb = th;
-            if (a >= BODY_FINGER1) cull = !(finger_zmin(ca, Ra) < tc[2] + th[2] + CONTACT_MARGIN);
-        } else {
-            cb = L.blk[b]; Rb = L.blkR[b]; hb = bh;
-            float dd[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
-            float lim = a >= BODY_FINGER1 ? 0.075f : 0.06f;
-            cull = dot3(dd, dd) > lim * lim;
-        }
+        float oh[3] = {ob.half[0], ob.half[1], ob.half[2]};
+        float* stage = &L.stage[i][0][0];
         int n = 0;
-        if (!cull) n = box_box_fast(ca, Ra, ha, cb, Rb, hb, CONTACT_MARGIN, &L.stage[i][0][0], L.work[i]);
+        if (a == BODY_GBASE) {
+            const float* gc = L.gbase;
+            float dd[3] = {gc[0] - L.blk[b][0], gc[1] - L.blk[b][1], gc[2] - L.blk[b][2]};
+            if (!(dot3(dd, dd) > 0.085f * 0.085f))
+                n = cyl_box(gc, gc + 3, (float)PMG_GBASE_RADIUS, (float)PMG_GBASE_HALFLEN, L.blk[b], L.blkR[b], oh, CONTACT_MARGIN, stage, L.work[i]);
+        } else if (a >= BODY_FINGER1) {
+            const float* fc = L.fing[a - BODY_FINGER1];
+            if (b == BODY_STATIC) {
+                if (finger_zmin(fc, fc + 3) < tc[2] + th[2] + CONTACT_MARGIN)
+                    n = box_box_fast(fc, fc + 3, fh, tc, I3, th, CONTACT_MARGIN, stage, L.work[i]);
+            } else {
+                float dd[3] = {fc[0] - L.blk[b][0], fc[1] - L.blk[b][1], fc[2] - L.blk[b][2]};
+                if (!(dot3(dd, dd) > 0.08f * 0.08f)) {
+                    if (!ob.cyl) n = box_box_fast(fc, fc + 3, fh, L.blk[b], L.blkR[b], oh, CONTACT_MARGIN, stage, L.work[i]);
+                    else {
+                        /* the puck is the cylinder: computed as A, then roles swapped (finger is A of the pair) */
+                        n = cyl_box(L.blk[b], L.blkR[b], oh[0], oh[2], fc, fc + 3, fh, CONTACT_MARGIN, stage, L.work[i]);
+                        for (int c = 0; c < n; c++) {
+                            float* o = stage + CP * c;
+                            for (int x = 0; x < 3; x++) { float t = o[x]; o[x] = o[3 + x]; o[3 + x] = t; o[6 + x] = -o[6 + x]; }
+                        }
+                    }
+                }
+            }
+        } else if (b == BODY_STATIC) {
+            if (!ob.cyl) n = box_box_fast(L.blk[a], L.blkR[a], oh, tc, I3, th, CONTACT_MARGIN, stage, L.work[i]);
+            else n = cyl_box(L.blk[a], L.blkR[a], oh[0], oh[2], tc, I3, th, CONTACT_MARGIN, stage, L.work[i]);
+        } else {
+            float dd[3] = {L.blk[a][0] - L.blk[b][0], L.blk[a][1] - L.blk[b][1], L.blk[a][2] - L.blk[b][2]};
+            if (!(dot3(dd, dd) > 0.06f * 0.06f))
+                n = box_box_fast(L.blk[a], L.blkR[a], oh, L.blk[b], L.blkR[b], oh, CONTACT_MARGIN, stage, L.work[i]);
+        }
         L.pair_count[i] = n;
     }
     wv::lds_sync();
@@ -497,20 +763,19 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
         int n = L.pair_count[i];
         int a, b;
         decode_pair<NB>(i, nb, a, b);
-        float mu = (a >= BODY_FINGER1 ? (float)PMG_FINGER_FRICTION : (float)PMG_BLOCK_FRICTION) *
-                   (b == BODY_STATIC ? table_mu : (float)PMG_BLOCK_FRICTION);
+        float mua = a == BODY_GBASE ? 0.5f : (a >= BODY_FINGER1 ? (float)PMG_FINGER_FRICTION : ob.mu);
+        float mu = mua * (b == BODY_STATIC ? table_mu : ob.mu);
         for (int c = 0; c < n && off + c < MAXC; c++) {
             float* o = L.con[off + c];
-            const float* s = L.stage[i][c];
+            const float* st = L.stage[i][c];
             o[0] = (float)a; o[1] = (float)b;
-            for (int k = 0; k < 10; k++) o[2 + k] = s[k];
+            for (int k = 0; k < 10; k++) o[2 + k] = st[k];
             L.con_mu[off + c] = mu;
         }
     }
     for (int j = 0; j < npair; j++) total += L.pair_count[j];
     if (total > MAXC) total = MAXC;
     wv::lds_sync();
-    (void)sizeof(LT);
     return total;
 }
 
@@ -528,7 +793,7 @@ __device__ __forceinline__ float* row_of(ContactLds<NB, MAXC>& L, int c, int t)
  *   R4 lane = contact:            1/diag, relative velocity, right-hand sides
  * ([BULLET-PRIOR] btMultiBodyConstraintSolver::setupMultiBodyContactConstraint) */
 template <int NB, int MAXC>
-__device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int nc)
+__device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int nc, const ObjParams& ob)
 {
     using LY = RowLayout<NB>;
     int l = wv::lane();
@@ -555,12 +820,22 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
                 cross3(r, dir, rxn);
                 float* J = row + 9 + (LY::direct ? 0 : 6 * s2);
                 for (int k = 0; k < 3; k++) { J[k] = sg * dir[k]; J[3 + k] = sg * rxn[k]; }
+                /* angular response R diag(1/I) R^T (r x dir): isotropic for the cubes, general for the puck */
+                float da[3] = {J[3] * ob.inv_inertia[0], J[4] * ob.inv_inertia[0], J[5] * ob.inv_inertia[0]};
+                if (ob.cyl) {
+                    float la[3];
+                    const float* Rm = L.blkR[id];
+                    la[0] = (Rm[0] * J[3] + Rm[3] * J[4] + Rm[6] * J[5]) * ob.inv_inertia[0];
+                    la[1] = (Rm[1] * J[3] + Rm[4] * J[4] + Rm[7] * J[5]) * ob.inv_inertia[1];
+                    la[2] = (Rm[2] * J[3] + Rm[5] * J[4] + Rm[8] * J[5]) * ob.inv_inertia[2];
+                    mat3v(Rm, la, da);
+                }
                 if (LY::direct) {
-                    for (int k = 0; k < 3; k++) { row[25 + k] = J[k] / BLOCK_MASS; row[28 + k] = J[3 + k] / BLOCK_INERTIA; }
+                    for (int k = 0; k < 3; k++) { row[25 + k] = J[k] / BLOCK_MASS; row[28 + k] = da[k]; }
                 } else {
                     row[SLOT_IDA + s2] = (float)id;
                 }
-                denom += dot3(J, J) / BLOCK_MASS + dot3(J + 3, J + 3) / BLOCK_INERTIA;
+                denom += dot3(J, J) / BLOCK_MASS + dot3(J + 3, da);
                 rel += dot3(J, bl + 7) + dot3(J + 3, bl + 10);
             }
             row[ROW_DINV] = denom;
@@ -578,7 +853,7 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
         for (int s2 = 0; s2 < 2; s2++) {
             int id = (int)o[s2];
             if (id < BODY_FINGER1) continue;
-            int own = id == BODY_FINGER1 ? 7 : 8;
+            int own = id == BODY_FINGER1 ? 7 : (id == BODY_FINGER2 ? 8 : -1); /* the gripper base rides on link 7 only */
             if (d >= 7 && d != own) continue;
             const float* S = L.S[d];
             const float* pt = o + 2 + 3 * s2;

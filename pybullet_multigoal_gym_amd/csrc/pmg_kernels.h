@@ -26,6 +26,7 @@ struct EnvParams {
     float thr;
     float ee_lo[3], ee_hi[3];
     float table_c[3], table_h[3], table_mu;
+    ObjParams obj;   /* free object(s): cubes or the slide puck */
     /* sampling boxes, kept in double so that the RNG draws reproduce numpy's float64 uniform() */
     double tip_init[3], obj_lo[3], obj_hi[3], tgt_lo[3], tgt_hi[3], obj_z;
     /* device arrays */
@@ -176,12 +177,13 @@ __device__ __noinline__ int collide_cold(ContactLds<NB, MAXC>& L, int nb, float 
                                          float thz, float tmu)
 {
     float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
-    return collide(L, nb, tc, th, tmu);
+    ObjParams ob = {0, {BLOCK_HALF, BLOCK_HALF, BLOCK_HALF}, {1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA}, (float)PMG_BLOCK_FRICTION};
+    return collide(L, nb, tc, th, tmu, ob);
 }
 /* publish (inline, from registers) what the pair / contact lanes need, then run the narrowphase */
 template <int NB, int MAXC>
 __device__ __forceinline__ int detect(ContactLds<NB, MAXC>& L, int nb, const Kin& k, float tcx, float tcy, float tcz, float thx,
-                                      float thy, float thz, float tmu)
+                                      float thy, float thz, float tmu, const ObjParams& ob)
 {
     int l = wv::lane();
     if (l == 7 || l == 8) {
@@ -195,20 +197,27 @@ __device__ __forceinline__ int detect(ContactLds<NB, MAXC>& L, int nb, const Kin
 #pragma unroll
         for (int a = 0; a < 6; a++) L.S[l][a] = k.S[a];
     }
+    if (NB > 0 && l == 6) { /* gripper-base cylinder: link 7 frame shifted 0.055 along its z (urdf:390-395) */
+#pragma unroll
+        for (int a = 0; a < 3; a++) L.gbase[a] = k.p[a] + k.R[3 * a + 2] * 0.055f;
+#pragma unroll
+        for (int a = 0; a < 9; a++) L.gbase[3 + a] = k.R[a];
+    }
     if (l < nb) quat_to_R(L.blk[l] + 3, L.blkR[l]);
     wv::lds_sync();
     if (PMG_COLD_CONTACTS && NB == 0) return collide_cold<NB, MAXC>(L, nb, tcx, tcy, tcz, thx, thy, thz, tmu);
     float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
-    return collide(L, nb, tc, th, tmu);
+    return collide(L, nb, tc, th, tmu, ob);
 }
 
 template <int NB, int MAXC>
 __device__ __noinline__ void build_rows_cold(ContactLds<NB, MAXC>& L, int nc)
 {
-    build_contact_rows(L, nc);
+    ObjParams ob = {0, {BLOCK_HALF, BLOCK_HALF, BLOCK_HALF}, {1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA}, (float)PMG_BLOCK_FRICTION};
+    build_contact_rows(L, nc, ob);
 }
 template <int NB, int MAXC>
-__device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const float* minv, float qd, int nc)
+__device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const float* minv, float qd, int nc, const ObjParams& ob)
 {
     int l = wv::lane();
     if (l < NJ) {
@@ -218,7 +227,7 @@ __device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const floa
     }
     wv::lds_sync();
     if (PMG_COLD_CONTACTS && NB == 0) build_rows_cold<NB, MAXC>(L, nc);
-    else build_contact_rows(L, nc);
+    else build_contact_rows(L, nc, ob);
 }
 
 /* reach: PGS iterations when finger x table contacts exist -- register-resident rows (RobotRows) */
@@ -259,7 +268,7 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
     int nc = 0;
     bool low = (l == 7 || l == 8) && (finger_zmin(k.p, k.R) < P.table_c[2] + P.table_h[2] + CONTACT_MARGIN);
     if (NB > 0 || wv::ballot(low) != 0ull)
-        nc = detect<NB, MAXC>(L, nb, k, P.table_c[0], P.table_c[1], P.table_c[2], P.table_h[0], P.table_h[1], P.table_h[2], P.table_mu);
+        nc = detect<NB, MAXC>(L, nb, k, P.table_c[0], P.table_c[1], P.table_c[2], P.table_h[0], P.table_h[1], P.table_h[2], P.table_mu, P.obj);
 
     PMG_TICK(1);
     /* unconstrained velocity update: robot (CRBA + RNEA) ... */
@@ -276,18 +285,33 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
 #pragma unroll
     for (int j = 0; j < NJ; j++) qdd += minv[j] * wv::bcast(rq, j);
     qd += DT * qdd;
-    /* ... and the free blocks: gravity + Bullet's base damping (isotropic inertia: no gyroscopic term) */
+    /* ... and the free objects: gravity, Bullet's base damping and the gyroscopic term w x (I w)
+     * (zero for the isotropic cubes, not for the slide puck) */
     if (l < nb) {
         float* b = L.blk[l];
+        const float* Rm = L.blkR[l];
         float kl = LINK_DAMPING * (1.f + sqrtf(dot3(b + 7, b + 7))), ka = LINK_DAMPING * (1.f + sqrtf(dot3(b + 10, b + 10)));
+        float al[3] = {-b[10] * ka, -b[11] * ka, -b[12] * ka};
+        if (P.obj.cyl) {
+            float wl[3], Iw[3], gy[3], tq[3];
+            wl[0] = Rm[0] * b[10] + Rm[3] * b[11] + Rm[6] * b[12];
+            wl[1] = Rm[1] * b[10] + Rm[4] * b[11] + Rm[7] * b[12];
+            wl[2] = Rm[2] * b[10] + Rm[5] * b[11] + Rm[8] * b[12];
+#pragma unroll
+            for (int a = 0; a < 3; a++) Iw[a] = wl[a] / P.obj.inv_inertia[a];
+            cross3(wl, Iw, gy);
+#pragma unroll
+            for (int a = 0; a < 3; a++) tq[a] = (-Iw[a] * ka - gy[a]) * P.obj.inv_inertia[a];
+            mat3v(Rm, tq, al);
+        }
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             b[7 + a] += DT * (-b[7 + a] * kl + (a == 2 ? -GRAVITY : 0.f));
-            b[10 + a] += DT * (-b[10 + a] * ka);
+            b[10 + a] += DT * al[a];
         }
     }
     PMG_TICK(2);
-    if (nc > 0) prepare_rows<NB, MAXC>(L, minv, qd, nc);
+    if (nc > 0) prepare_rows<NB, MAXC>(L, minv, qd, nc, P.obj);
     PMG_TICK(3);
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);

@@ -190,6 +190,15 @@ def box_box(ca, Ra, ha, cb, Rb, hb, margin=0.002, f32=False):
     return out.reshape(4, 10)[:n]
 
 
+def cyl_box(cc, Rc, rad, hl, cb, Rb, hb, margin=0.002, f32=False):
+    lib = load(f32)
+    a = [np.ascontiguousarray(x, np.float64) for x in (cc, Rc, cb, Rb, hb)]
+    out = np.zeros(40)
+    lib.pmgo_cyl_box.restype = C.c_int
+    n = lib.pmgo_cyl_box(_fp(a[0]), _fp(a[1]), C.c_double(rad), C.c_double(hl), _fp(a[2]), _fp(a[3]), _fp(a[4]), C.c_double(margin), _fp(out))
+    return out.reshape(4, 10)[:n]
+
+
 def rng_probe(seed, n_double, shuffle_n=0):
     lib = load()
     d = np.zeros(max(n_double, 1))

@@ -65,3 +65,49 @@ def test_emulated_step_kernel_matches_oracle(emu_library, task, kw, steps, tol):
     assert np.abs(o['achieved_goal'] - oo['achieved_goal']).max() < tol
     assert np.array_equal(r, ro) and np.array_equal(d, do)
     env.close()
+
+
+def _pair(emu_library, task, **kw):
+    env = pmg.make_env(task=task, num_envs=1, seed=3, seed_stride=1, _library=emu_library, **kw)
+    ora = O.OracleEnv(task, 1, seed_base=3, seed_stride=1, **kw)
+    ora.reset()
+    env.reset(), ora.reset()
+    assert np.abs(env.get_state() - ora.get_state()).max() < 1e-6
+    return env, ora
+
+
+def _drive(env, ora, actions):
+    for a in actions:
+        a = np.float32(a).reshape(1, -1)
+        o, r, d, _ = env.step(a)
+        oo, ro, do, _ = ora.step(a)
+    se, so = env.get_state()[0], ora.get_state()[0]
+    assert np.abs(se[:9] - so[:9]).max() < 2e-5                 # joint angles
+    assert np.abs(se[64:71] - so[64:71]).max() < 5e-5           # object pose
+    assert np.abs(se[71:77] - so[71:77]).max() < 2e-3           # object twist (solver early-exit floor)
+    assert np.array_equal(r, ro) and np.array_equal(d, do)
+    return so
+
+
+def test_emulated_slide_puck_matches_oracle(emu_library):
+    """cylinder x box narrowphase on the device: the puck resting on the long table (mu 0.05), then pushed by
+    the closed fingers (kuka_single_step_base_env.py:53-56,66-69; cylinder_bulk.urdf)."""
+    env, ora = _pair(emu_library, 'slide')
+    assert np.array_equal(env.reset()['desired_goal'], ora.reset()['desired_goal'])
+    st = ora.get_state().copy()
+    st[0, 64:67] = [-0.52, 0.045, 0.170]
+    env.set_state(st), ora.set_state(st)
+    so = _drive(env, ora, [[0, 1, 0], [0, 1, 0]])
+    assert so[65] > 0.06 and abs(so[66] - 0.170) < 1e-4        # it moved along +y and stayed on the table
+    env.close()
+
+
+def test_emulated_gripper_base_contact_matches_oracle(emu_library):
+    """gripper-base cylinder (link 7) x block pairs: a block wedged between the open fingers against the palm."""
+    env, ora = _pair(emu_library, 'pick_and_place')
+    st = ora.get_state().copy()
+    st[0, 64:67] = [-0.52, 0.0, 0.25 + 0.0295]
+    env.set_state(st), ora.set_state(st)
+    so = _drive(env, ora, [[0, 0, 0, 1], [0, 0, -1, 1]])
+    assert so[66] > 0.25                                         # held up by the contacts, not in free fall
+    env.close()

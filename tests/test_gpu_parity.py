@@ -90,7 +90,7 @@ def test_compute_reward_batch(built):
 
 
 @pytest.mark.parametrize('task,kw', [('push', {}), ('pick_and_place', {}), ('pick_and_place', {'binary_reward': False}),
-                                     ('block_stack', {'num_block': 4})])
+                                     ('slide', {}), ('block_stack', {'num_block': 4})])
 def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task, kw):
     """Contact-rich rollouts are chaotic and the PGS early exit makes velocities only ~3e-4 exact, so
     the HIP path is held to the float64 oracle within a small multiple of the oracle's OWN
@@ -123,6 +123,42 @@ def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task,
     else:
         assert np.percentile(np.abs(r - r64), 90) < 2e-3 and r.dtype == np.float32
     assert o['observation'].shape == (N, env.dims.observation_dim) and np.isfinite(o['observation']).all()
+    env.close()
+
+
+@pytest.mark.parametrize('scenario', ['slide_push', 'palm_block'])
+def test_constructed_cylinder_contacts_match_oracle(built, scenario):
+    """cylinder x box pairs on the device, in configurations random policies rarely reach within 10 steps: the
+    slide puck pushed by the closed fingers, and a block wedged between the open fingers against the gripper-base
+    cylinder.  32 envs with slightly different object offsets; positions after two env steps (200 substeps)."""
+    N = 32
+    task = 'slide' if scenario == 'slide_push' else 'pick_and_place'
+    env, ora = _pair(task, N)
+    o32 = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=8, f32=True)
+    o32.reset()
+    env.reset(), ora.reset(), o32.reset()
+    st = ora.get_state().copy()
+    off = np.random.RandomState(1).uniform(-0.004, 0.004, (N, 2)).astype(np.float32)
+    if scenario == 'slide_push':
+        st[:, 64] = -0.52 + off[:, 0]; st[:, 65] = 0.045 + off[:, 1]; st[:, 66] = 0.170
+        acts = [[0, 1, 0], [0, 1, 0]]
+    else:
+        st[:, 64] = -0.52 + off[:, 0]; st[:, 65] = off[:, 1] * 0.25; st[:, 66] = 0.25 + 0.0295
+        acts = [[0, 0, 0, 1], [0, 0, -1, 1]]
+    st[:, 67:71] = [0, 0, 0, 1]; st[:, 71:77] = 0
+    env.set_state(st), ora.set_state(st), o32.set_state(st)
+    for a in acts:
+        a = np.tile(np.float32(a), (N, 1))
+        env.step(a), ora.step(a), o32.step(a)
+    se, so, s32 = env.get_state(), ora.get_state(), o32.get_state()
+    # bar: the oracle's own float32-vs-float64 spread on the same scenario (solver early-exit floor)
+    for cols in (slice(0, 9), slice(64, 67)):
+        err, spread = np.abs(se[:, cols] - so[:, cols]).max(1), np.abs(s32[:, cols] - so[:, cols]).max(1)
+        assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4, (cols, np.percentile(err, 90), np.percentile(spread, 90))
+    if scenario == 'slide_push':
+        assert (so[:, 65] > 0.055).all() and np.abs(so[:, 66] - 0.170).max() < 1e-3   # pushed along +y, still on the table
+    else:
+        assert (so[:, 66] > 0.25).mean() > 0.9                                          # held by the contacts
     env.close()
 
 

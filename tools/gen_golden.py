@@ -37,13 +37,17 @@ def gym_np_random(seed):
 
 def boxes(task):
     tip = np.array([-0.52, 0.0, 0.25])
-    if task == 'push':
+    if task in ('push', 'slide'):
         tip[-1] = 0.175 + 0.001
     lower = np.array([-0.67, -0.20, 0.175])
-    obj_lo, obj_hi = tip.copy() - 0.15, tip.copy() + 0.15
+    # kuka_single_step_envs.py:14,29,44,57: slide is built with obj_range=0.1, target_range=0.2 (the others 0.15 / 0.15)
+    obj_range, tgt_range = (0.1, 0.2) if task == 'slide' else (0.15, 0.15)
+    obj_lo, obj_hi = tip.copy() - obj_range, tip.copy() + obj_range
     obj_lo[0] += 0.03; obj_hi[0] -= 0.03
-    tgt_lo, tgt_hi = tip.copy() - 0.15, tip.copy() + 0.15
+    tgt_lo, tgt_hi = tip.copy() - tgt_range, tip.copy() + tgt_range
     tgt_lo[0] += 0.03; tgt_lo[-1] = lower[-1]; tgt_hi[0] -= 0.03
+    if task == 'slide':  # kuka_single_step_base_env.py:66-69
+        tgt_lo[0] -= 0.4; tgt_hi[0] -= 0.4
     return tip, obj_lo, obj_hi, tgt_lo, tgt_hi
 
 
@@ -52,21 +56,22 @@ def single_reset(rs, task):
     has_obj, grasping, in_air = task != 'reach', task == 'pick_and_place', task in ('reach', 'pick_and_place')
     obj = None
     center = tip.copy()
+    obj_z = 0.170 if task == 'slide' else 0.175   # kuka_single_step_base_env.py:49,56
     if has_obj:
         xy = tip[:2]
         while np.linalg.norm(xy - tip[:2]) < 0.1:
             xy = rs.uniform(obj_lo[:-1], obj_hi[:-1])
-        obj = np.append(xy, 0.175)
+        obj = np.append(xy, obj_z)
         center = obj
     while True:
         g = rs.uniform(tgt_lo, tgt_hi)
         if np.linalg.norm(g - center) > 0.1:
             break
     if not in_air:
-        g[2] = 0.175
+        g[2] = obj_z
     elif grasping:
         if rs.uniform(0, 1) >= 0.5:
-            g[2] = 0.175
+            g[2] = obj_z
     return obj, g
 
 
@@ -103,7 +108,7 @@ def main():
     json.dump(rng, open(os.path.join(OUT, 'rng.json'), 'w'), indent=0)
 
     samp = {}
-    for task in ['reach', 'push', 'pick_and_place']:
+    for task in ['reach', 'push', 'pick_and_place', 'slide']:
         for seed in [0, 3]:
             rs, _ = gym_np_random(seed)
             eps = []
