@@ -96,6 +96,7 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--episode-steps', type=int, default=50)
+    ap.add_argument('--lib', default=None, help='alternative libpmg_hip.so build (kernel A/B experiments)')
     args = ap.parse_args()
 
     import pybullet_multigoal_gym_amd as pmg
@@ -112,8 +113,10 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
 
     N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, args.episode_steps
+    from pybullet_multigoal_gym_amd._lib import PmgLibrary
     env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=local_rank, seed=0, seed_stride=1,
-                       env_index_offset=rank * N, max_episode_steps=T)
+                       env_index_offset=rank * N, max_episode_steps=T,
+                       _library=PmgLibrary(args.lib) if args.lib else None)
     h = env.handle
     A = env.dims.action_dim
     gathered = None

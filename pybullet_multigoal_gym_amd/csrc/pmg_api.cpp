@@ -188,19 +188,13 @@ void fill_params(pmg_env* e)
     P.table_c[0] = -0.52f; P.table_c[1] = 0.f; P.table_c[2] = 0.08f;
     for (int a = 0; a < 3; a++) P.table_h[a] = th[a];
     P.table_mu = (float)PMG_TABLE_FRICTION;
-    P.obj.cyl = 0;
-    P.obj.mu = (float)PMG_BLOCK_FRICTION;
-    for (int a = 0; a < 3; a++) { P.obj.half[a] = pmg::BLOCK_HALF; P.obj.inv_inertia[a] = 1.f / pmg::BLOCK_INERTIA; }
-    if (t == PMG_TASK_SLIDE) { /* long table + puck: kuka_single_step_base_env.py:53-56, cylinder_bulk.urdf, table_long.urdf */
-        const float lt[3] = PMG_LONG_TABLE_HALF, ph[3] = PMG_PUCK_HALF;
-        const double pi[3] = PMG_PUCK_INERTIA;
+    if (t == PMG_TASK_SLIDE) { /* long table (table_long.urdf), kuka_single_step_base_env.py:53-56; the puck itself is pmg::ObjT<true> */
+        const float lt[3] = PMG_LONG_TABLE_HALF;
         P.tgt_lo[0] -= 0.4; P.tgt_hi[0] -= 0.4;
         P.table_c[0] = -0.70f;
-        for (int a = 0; a < 3; a++) { P.table_h[a] = lt[a]; P.obj.half[a] = ph[a]; P.obj.inv_inertia[a] = (float)(1.0 / pi[a]); }
+        for (int a = 0; a < 3; a++) P.table_h[a] = lt[a];
         P.table_mu = (float)PMG_LONG_TABLE_FRICTION;
         P.obj_z = 0.170;
-        P.obj.cyl = 1;
-        P.obj.mu = (float)PMG_PUCK_FRICTION;
     }
 }
 

@@ -422,11 +422,11 @@ __device__ inline int reduce4(const float (*pts)[3], const float* sep, int m, in
     if (i3 >= 0) sel[ns++] = i3;
     return ns;
 }
-__device__ __noinline__ inline int cyl_box(const float* cc, const float* Rc, float rad, float hl, const float* cb, const float* Rb,
-                              const float* hb_in, float margin, float* out, float* W)
+__device__ __forceinline__ int cyl_box(const float* cc, const float* Rc, float rad, float hl, const float* cb, const float* Rb,
+                                           float hbx, float hby, float hbz, float margin, float* out, float* W)
 {
     float a[3] = {Rc[2], Rc[5], Rc[8]}, u[3] = {Rc[0], Rc[3], Rc[6]}, v[3] = {Rc[1], Rc[4], Rc[7]};
-    float B[3][3], hb[3] = {hb_in[0], hb_in[1], hb_in[2]};
+    float B[3][3], hb[3] = {hbx, hby, hbz}; /* extents by value: the (cold) call never forces a caller array onto the stack */
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
@@ -698,60 +698,98 @@ __device__ __forceinline__ float finger_zmin(const float* c, const float* R)
 }
 
 /* collision detection for every candidate pair of this env; fills L.con / L.ncon (uniform) */
-/* per-task properties of the free object(s): the 3 cm blocks, or the slide puck (cylinder_bulk.urdf) */
-struct ObjParams {
-    int cyl;              /* 1: cylinder (half = r, r, h/2) */
-    float half[3];
-    float inv_inertia[3]; /* principal, body frame */
-    float mu;
+/* compile-time properties of the free object(s): the 3 cm cubes (block.urdf) or the slide puck
+ * (cylinder_bulk.urdf; half = r, r, h/2).  A template parameter rather than kernel arguments so the
+ * box tasks keep their constant-folded extents and scalar-register budget. */
+template <bool CYL>
+struct ObjT {
+    static constexpr bool cyl = CYL;
+    static constexpr float mu = CYL ? (float)PMG_PUCK_FRICTION : (float)PMG_BLOCK_FRICTION;
+    __host__ __device__ static constexpr float half(int a)
+    {
+        constexpr float ph[3] = PMG_PUCK_HALF;
+        return CYL ? ph[a] : BLOCK_HALF;
+    }
+    __host__ __device__ static constexpr float inv_inertia(int a) /* principal, body frame */
+    {
+        constexpr double pi[3] = PMG_PUCK_INERTIA;
+        return CYL ? (float)(1.0 / pi[a]) : 1.f / BLOCK_INERTIA;
+    }
 };
 
-template <int NB, int MAXC>
-__device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const float* table_c, const float* table_h, float table_mu,
-                                       const ObjParams& ob)
+template <int NB, int MAXC, bool CYL>
+__device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const float* table_c, const float* table_h, float table_mu)
 {
+    using OB = ObjT<CYL>;
     int l = wv::lane();
-    int npair = nb + nb * (nb - 1) / 2 + 2 * (nb + 1) + (ob.cyl ? 0 : nb);
+    int npair = nb + nb * (nb - 1) / 2 + 2 * (nb + 1) + (OB::cyl ? 0 : nb);
     const float I3[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     const float fh[3] = PMG_FINGER_HALF;
+    const float oh[3] = {OB::half(0), OB::half(1), OB::half(2)};
     for (int i = l; i < npair; i += 64) {
         int a, b;
         decode_pair<NB>(i, nb, a, b);
         float tc[3] = {table_c[0], table_c[1], table_c[2]}, th[3] = {table_h[0], table_h[1], table_h[2]};
-        float oh[3] = {ob.half[0], ob.half[1], ob.half[2]};
-        float* stage = &L.stage[i][0][0];
-        int n = 0;
+        /* every pair funnels into ONE box_box_fast and ONE cyl_box call site, so the lanes of a wave run the
+         * narrowphase together instead of once per pair type.  kind: -1 culled, 0 box x box, 1 cylinder(A) x box(B);
+         * swapped: the cylinder is body B of the pair (finger x puck), roles exchanged afterwards */
+        const float *ca, *Ra, *ha, *cb, *Rb, *hb;
+        int kind = 0;
+        bool swapped = false;
+        float rad = oh[0], hl = oh[2];
         if (a == BODY_GBASE) {
-            const float* gc = L.gbase;
-            float dd[3] = {gc[0] - L.blk[b][0], gc[1] - L.blk[b][1], gc[2] - L.blk[b][2]};
-            if (!(dot3(dd, dd) > 0.085f * 0.085f))
-                n = cyl_box(gc, gc + 3, (float)PMG_GBASE_RADIUS, (float)PMG_GBASE_HALFLEN, L.blk[b], L.blkR[b], oh, CONTACT_MARGIN, stage, L.work[i]);
+            ca = L.gbase; Ra = L.gbase + 3; ha = oh; rad = (float)PMG_GBASE_RADIUS; hl = (float)PMG_GBASE_HALFLEN;
+            cb = L.blk[b]; Rb = L.blkR[b]; hb = oh;
+            /* cull in the cylinder frame: axial and radial slabs grown by the block's bounding sphere */
+            constexpr float rb = 0.026f + CONTACT_MARGIN;
+            constexpr float rlim = (float)PMG_GBASE_RADIUS + rb;
+            float dd[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+            float az = Ra[2] * dd[0] + Ra[5] * dd[1] + Ra[8] * dd[2];
+            float r2 = dot3(dd, dd) - az * az;
+            kind = (fabsf(az) <= (float)PMG_GBASE_HALFLEN + rb && r2 <= rlim * rlim) ? 1 : -1;
         } else if (a >= BODY_FINGER1) {
-            const float* fc = L.fing[a - BODY_FINGER1];
+            ca = L.fing[a - BODY_FINGER1]; Ra = ca + 3; ha = fh;
             if (b == BODY_STATIC) {
-                if (finger_zmin(fc, fc + 3) < tc[2] + th[2] + CONTACT_MARGIN)
-                    n = box_box_fast(fc, fc + 3, fh, tc, I3, th, CONTACT_MARGIN, stage, L.work[i]);
+                cb = tc; Rb = I3; hb = th;
+                if (!(finger_zmin(ca, Ra) < tc[2] + th[2] + CONTACT_MARGIN)) kind = -1;
             } else {
-                float dd[3] = {fc[0] - L.blk[b][0], fc[1] - L.blk[b][1], fc[2] - L.blk[b][2]};
-                if (!(dot3(dd, dd) > 0.08f * 0.08f)) {
-                    if (!ob.cyl) n = box_box_fast(fc, fc + 3, fh, L.blk[b], L.blkR[b], oh, CONTACT_MARGIN, stage, L.work[i]);
-                    else {
-                        /* the puck is the cylinder: computed as A, then roles swapped (finger is A of the pair) */
-                        n = cyl_box(L.blk[b], L.blkR[b], oh[0], oh[2], fc, fc + 3, fh, CONTACT_MARGIN, stage, L.work[i]);
-                        for (int c = 0; c < n; c++) {
-                            float* o = stage + CP * c;
-                            for (int x = 0; x < 3; x++) { float t = o[x]; o[x] = o[3 + x]; o[3 + x] = t; o[6 + x] = -o[6 + x]; }
-                        }
-                    }
+                cb = L.blk[b]; Rb = L.blkR[b]; hb = oh;
+                /* cull in the finger frame: object bounding sphere against the finger box grown by it (conservative
+                 * -- an excluded pair has a finger face axis separating it by more than the margin) */
+                constexpr float rb = (CYL ? 0.0317f : 0.026f) + CONTACT_MARGIN;
+                float dd[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+                float lx = Ra[0] * dd[0] + Ra[3] * dd[1] + Ra[6] * dd[2];
+                float ly = Ra[1] * dd[0] + Ra[4] * dd[1] + Ra[7] * dd[2];
+                float lz = Ra[2] * dd[0] + Ra[5] * dd[1] + Ra[8] * dd[2];
+                if (!(fabsf(lx) <= fh[0] + rb && fabsf(ly) <= fh[1] + rb && fabsf(lz) <= fh[2] + rb)) kind = -1;
+                else if (CYL) { /* the puck is the cylinder: run it as A, exchange roles afterwards */
+                    kind = 1; swapped = true;
+                    const float* t;
+                    t = ca; ca = cb; cb = t;
+                    t = Ra; Ra = Rb; Rb = t;
+                    hb = fh;
                 }
             }
         } else if (b == BODY_STATIC) {
-            if (!ob.cyl) n = box_box_fast(L.blk[a], L.blkR[a], oh, tc, I3, th, CONTACT_MARGIN, stage, L.work[i]);
-            else n = cyl_box(L.blk[a], L.blkR[a], oh[0], oh[2], tc, I3, th, CONTACT_MARGIN, stage, L.work[i]);
+            ca = L.blk[a]; Ra = L.blkR[a]; ha = oh;
+            cb = tc; Rb = I3; hb = th;
+            kind = CYL ? 1 : 0;
         } else {
-            float dd[3] = {L.blk[a][0] - L.blk[b][0], L.blk[a][1] - L.blk[b][1], L.blk[a][2] - L.blk[b][2]};
-            if (!(dot3(dd, dd) > 0.06f * 0.06f))
-                n = box_box_fast(L.blk[a], L.blkR[a], oh, L.blk[b], L.blkR[b], oh, CONTACT_MARGIN, stage, L.work[i]);
+            ca = L.blk[a]; Ra = L.blkR[a]; ha = oh;
+            cb = L.blk[b]; Rb = L.blkR[b]; hb = oh;
+            float dd[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+            if (dot3(dd, dd) > 0.06f * 0.06f) kind = -1;
+        }
+        float* stage = &L.stage[i][0][0];
+        int n = 0;
+        if (kind == 0) n = box_box_fast(ca, Ra, ha, cb, Rb, hb, CONTACT_MARGIN, stage, L.work[i]);
+        if (kind == 1) {
+            n = cyl_box(ca, Ra, rad, hl, cb, Rb, hb[0], hb[1], hb[2], CONTACT_MARGIN, stage, L.work[i]);
+            if (swapped)
+                for (int c = 0; c < n; c++) {
+                    float* o = stage + CP * c;
+                    for (int x = 0; x < 3; x++) { float t = o[x]; o[x] = o[3 + x]; o[3 + x] = t; o[6 + x] = -o[6 + x]; }
+                }
         }
         L.pair_count[i] = n;
     }
@@ -763,8 +801,8 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
         int n = L.pair_count[i];
         int a, b;
         decode_pair<NB>(i, nb, a, b);
-        float mua = a == BODY_GBASE ? 0.5f : (a >= BODY_FINGER1 ? (float)PMG_FINGER_FRICTION : ob.mu);
-        float mu = mua * (b == BODY_STATIC ? table_mu : ob.mu);
+        float mua = a == BODY_GBASE ? 0.5f : (a >= BODY_FINGER1 ? (float)PMG_FINGER_FRICTION : OB::mu);
+        float mu = mua * (b == BODY_STATIC ? table_mu : OB::mu);
         for (int c = 0; c < n && off + c < MAXC; c++) {
             float* o = L.con[off + c];
             const float* st = L.stage[i][c];
@@ -792,9 +830,10 @@ __device__ __forceinline__ float* row_of(ContactLds<NB, MAXC>& L, int c, int t)
  *   R3 lane = (row, DoF) item:    (M^-1 J^T)[r][i] = sum_j M^-1[i][j] J[r][j]
  *   R4 lane = contact:            1/diag, relative velocity, right-hand sides
  * ([BULLET-PRIOR] btMultiBodyConstraintSolver::setupMultiBodyContactConstraint) */
-template <int NB, int MAXC>
-__device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int nc, const ObjParams& ob)
+template <int NB, int MAXC, bool CYL>
+__device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int nc)
 {
+    using OB = ObjT<CYL>;
     using LY = RowLayout<NB>;
     int l = wv::lane();
     /* R1 */
@@ -821,13 +860,13 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
                 float* J = row + 9 + (LY::direct ? 0 : 6 * s2);
                 for (int k = 0; k < 3; k++) { J[k] = sg * dir[k]; J[3 + k] = sg * rxn[k]; }
                 /* angular response R diag(1/I) R^T (r x dir): isotropic for the cubes, general for the puck */
-                float da[3] = {J[3] * ob.inv_inertia[0], J[4] * ob.inv_inertia[0], J[5] * ob.inv_inertia[0]};
-                if (ob.cyl) {
+                float da[3] = {J[3] * OB::inv_inertia(0), J[4] * OB::inv_inertia(0), J[5] * OB::inv_inertia(0)};
+                if (OB::cyl) {
                     float la[3];
                     const float* Rm = L.blkR[id];
-                    la[0] = (Rm[0] * J[3] + Rm[3] * J[4] + Rm[6] * J[5]) * ob.inv_inertia[0];
-                    la[1] = (Rm[1] * J[3] + Rm[4] * J[4] + Rm[7] * J[5]) * ob.inv_inertia[1];
-                    la[2] = (Rm[2] * J[3] + Rm[5] * J[4] + Rm[8] * J[5]) * ob.inv_inertia[2];
+                    la[0] = (Rm[0] * J[3] + Rm[3] * J[4] + Rm[6] * J[5]) * OB::inv_inertia(0);
+                    la[1] = (Rm[1] * J[3] + Rm[4] * J[4] + Rm[7] * J[5]) * OB::inv_inertia(1);
+                    la[2] = (Rm[2] * J[3] + Rm[5] * J[4] + Rm[8] * J[5]) * OB::inv_inertia(2);
                     mat3v(Rm, la, da);
                 }
                 if (LY::direct) {

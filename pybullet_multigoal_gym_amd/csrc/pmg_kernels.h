@@ -26,7 +26,6 @@ struct EnvParams {
     float thr;
     float ee_lo[3], ee_hi[3];
     float table_c[3], table_h[3], table_mu;
-    ObjParams obj;   /* free object(s): cubes or the slide puck */
     /* sampling boxes, kept in double so that the RNG draws reproduce numpy's float64 uniform() */
     double tip_init[3], obj_lo[3], obj_hi[3], tgt_lo[3], tgt_hi[3], obj_z;
     /* device arrays */
@@ -177,13 +176,12 @@ __device__ __noinline__ int collide_cold(ContactLds<NB, MAXC>& L, int nb, float 
                                          float thz, float tmu)
 {
     float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
-    ObjParams ob = {0, {BLOCK_HALF, BLOCK_HALF, BLOCK_HALF}, {1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA}, (float)PMG_BLOCK_FRICTION};
-    return collide(L, nb, tc, th, tmu, ob);
+    return collide<NB, MAXC, false>(L, nb, tc, th, tmu);
 }
 /* publish (inline, from registers) what the pair / contact lanes need, then run the narrowphase */
-template <int NB, int MAXC>
+template <int NB, int MAXC, bool CYL>
 __device__ __forceinline__ int detect(ContactLds<NB, MAXC>& L, int nb, const Kin& k, float tcx, float tcy, float tcz, float thx,
-                                      float thy, float thz, float tmu, const ObjParams& ob)
+                                      float thy, float thz, float tmu)
 {
     int l = wv::lane();
     if (l == 7 || l == 8) {
@@ -207,17 +205,16 @@ __device__ __forceinline__ int detect(ContactLds<NB, MAXC>& L, int nb, const Kin
     wv::lds_sync();
     if (PMG_COLD_CONTACTS && NB == 0) return collide_cold<NB, MAXC>(L, nb, tcx, tcy, tcz, thx, thy, thz, tmu);
     float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
-    return collide(L, nb, tc, th, tmu, ob);
+    return collide<NB, MAXC, CYL>(L, nb, tc, th, tmu);
 }
 
 template <int NB, int MAXC>
 __device__ __noinline__ void build_rows_cold(ContactLds<NB, MAXC>& L, int nc)
 {
-    ObjParams ob = {0, {BLOCK_HALF, BLOCK_HALF, BLOCK_HALF}, {1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA, 1.f / BLOCK_INERTIA}, (float)PMG_BLOCK_FRICTION};
-    build_contact_rows(L, nc, ob);
+    build_contact_rows<NB, MAXC, false>(L, nc);
 }
-template <int NB, int MAXC>
-__device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const float* minv, float qd, int nc, const ObjParams& ob)
+template <int NB, int MAXC, bool CYL>
+__device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const float* minv, float qd, int nc)
 {
     int l = wv::lane();
     if (l < NJ) {
@@ -227,7 +224,7 @@ __device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const floa
     }
     wv::lds_sync();
     if (PMG_COLD_CONTACTS && NB == 0) build_rows_cold<NB, MAXC>(L, nc);
-    else build_contact_rows(L, nc, ob);
+    else build_contact_rows<NB, MAXC, CYL>(L, nc);
 }
 
 /* reach: PGS iterations when finger x table contacts exist -- register-resident rows (RobotRows) */
@@ -250,7 +247,7 @@ __device__ __forceinline__ void reach_contact_pgs(ContactLds<NB, MAXC>& L, int n
 /* ------------------------------------------------------------------ */
 /* one 2 ms substep: collide, unconstrained velocities, PGS rows, integrate
  * ([BULLET-PRIOR] btMultiBodyDynamicsWorld::internalSingleStepSimulation)  */
-template <int NB, int MAXC>
+template <int NB, int MAXC, bool CYL>
 __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>& L, const LaneConst& c_in, float& q, float& qd,
                                         float tau, float mtarget, float mimp)
 {
@@ -268,7 +265,7 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
     int nc = 0;
     bool low = (l == 7 || l == 8) && (finger_zmin(k.p, k.R) < P.table_c[2] + P.table_h[2] + CONTACT_MARGIN);
     if (NB > 0 || wv::ballot(low) != 0ull)
-        nc = detect<NB, MAXC>(L, nb, k, P.table_c[0], P.table_c[1], P.table_c[2], P.table_h[0], P.table_h[1], P.table_h[2], P.table_mu, P.obj);
+        nc = detect<NB, MAXC, CYL>(L, nb, k, P.table_c[0], P.table_c[1], P.table_c[2], P.table_h[0], P.table_h[1], P.table_h[2], P.table_mu);
 
     PMG_TICK(1);
     /* unconstrained velocity update: robot (CRBA + RNEA) ... */
@@ -292,16 +289,16 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
         const float* Rm = L.blkR[l];
         float kl = LINK_DAMPING * (1.f + sqrtf(dot3(b + 7, b + 7))), ka = LINK_DAMPING * (1.f + sqrtf(dot3(b + 10, b + 10)));
         float al[3] = {-b[10] * ka, -b[11] * ka, -b[12] * ka};
-        if (P.obj.cyl) {
+        if (CYL) {
             float wl[3], Iw[3], gy[3], tq[3];
             wl[0] = Rm[0] * b[10] + Rm[3] * b[11] + Rm[6] * b[12];
             wl[1] = Rm[1] * b[10] + Rm[4] * b[11] + Rm[7] * b[12];
             wl[2] = Rm[2] * b[10] + Rm[5] * b[11] + Rm[8] * b[12];
 #pragma unroll
-            for (int a = 0; a < 3; a++) Iw[a] = wl[a] / P.obj.inv_inertia[a];
+            for (int a = 0; a < 3; a++) Iw[a] = wl[a] / ObjT<CYL>::inv_inertia(a);
             cross3(wl, Iw, gy);
 #pragma unroll
-            for (int a = 0; a < 3; a++) tq[a] = (-Iw[a] * ka - gy[a]) * P.obj.inv_inertia[a];
+            for (int a = 0; a < 3; a++) tq[a] = (-Iw[a] * ka - gy[a]) * ObjT<CYL>::inv_inertia(a);
             mat3v(Rm, tq, al);
         }
 #pragma unroll
@@ -311,7 +308,7 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
         }
     }
     PMG_TICK(2);
-    if (nc > 0) prepare_rows<NB, MAXC>(L, minv, qd, nc, P.obj);
+    if (nc > 0) prepare_rows<NB, MAXC, CYL>(L, minv, qd, nc);
     PMG_TICK(3);
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
@@ -428,7 +425,7 @@ __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
 
 /* ------------------------------------------------------------------ */
 /* env.step(): kuka.py:167-225 + _get_obs + _compute_reward + TimeLimit */
-template <int NB, int MAXC>
+template <int NB, int MAXC, bool CYL>
 __device__ __forceinline__ void step_env(const EnvParams& P, const float* actions)
 {
     __shared__ ContactLds<NB, MAXC> L;
@@ -471,7 +468,7 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
     PMG_TICK(5);
     for (int s = 0; s < SIM_STEPS; s++) {  /* kuka.py:223-225 */
         float tau = -c.jdamp() * qd;         /* joint damping latched per stepSimulation */
-        for (int ss = 0; ss < SUBSTEPS; ss++) substep<NB, MAXC>(P, L, c, q, qd, tau, mtarget, mimp);
+        for (int ss = 0; ss < SUBSTEPS; ss++) substep<NB, MAXC, CYL>(P, L, c, q, qd, tau, mtarget, mimp);
     }
     PMG_TICK(6);
     elapsed++;

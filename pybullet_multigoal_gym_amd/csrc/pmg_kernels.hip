@@ -11,11 +11,12 @@
 #define PMG_WAVES_PER_EU 2 /* the path is VALU-issue bound from 2 waves/SIMD on (profiles/r01): prefer 256 VGPRs and no spills */
 #endif
 
-/* three LDS footprints: reach (no blocks), one object (push / pick_and_place), block_stack (<= 5 blocks) */
-template <int NB, int MAXC>
+/* three LDS footprints: reach (no blocks), one object (push / pick_and_place / slide), block_stack (<= 5 blocks);
+ * CYL: the one object is the slide puck (cylinder x box pairs, anisotropic inertia) */
+template <int NB, int MAXC, bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
 {
-    pmg::step_env<NB, MAXC>(P, actions);
+    pmg::step_env<NB, MAXC, CYL>(P, actions);
 }
 
 __global__ void __launch_bounds__(1024) pmg_k_plan(pmg::EnvParams P, const float* __restrict__ actions)
@@ -80,9 +81,10 @@ hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipS
 }
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
-    else if (P.nb == 1) hipLaunchKernelGGL((pmg_k_step<1, 24>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
-    else hipLaunchKernelGGL((pmg_k_step<5, 48>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    else if (P.task == PMG_TASK_SLIDE) hipLaunchKernelGGL((pmg_k_step<1, 24, true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    else if (P.nb == 1) hipLaunchKernelGGL((pmg_k_step<1, 24, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    else hipLaunchKernelGGL((pmg_k_step<5, 48, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     return hipGetLastError();
 }
 hipError_t pmg_launch_reset(const pmg::EnvParams& P, const unsigned char* d_mask, hipStream_t s)

@@ -6,7 +6,7 @@
 #include <cstring>
 #include "pmg_kernels.h"
 template <int NB, int MAXC>
-__global__ void __launch_bounds__(64, 2) k_prof(pmg::EnvParams P, const float* act) { pmg::step_env<NB, MAXC>(P, act); }
+__global__ void __launch_bounds__(64, 2) k_prof(pmg::EnvParams P, const float* act) { pmg::step_env<NB, MAXC, false>(P, act); }
 int main(int argc, char** argv)
 {
     int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push
