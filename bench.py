@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # algorithmic bytes per env-step (state r+w, action, outputs)
-ALGO_BYTES = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246}
+ALGO_BYTES = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 

@@ -30,13 +30,14 @@
 extern "C" {
 #endif
 
-/* tasks: P/__init__.py:14-35 ('reach','push','pick_and_place','slide','block_stack') */
+/* tasks: P/__init__.py:14-40 ('reach','push','pick_and_place','slide','block_stack','block_rearrange') */
 enum {
     PMG_TASK_REACH = 0,
     PMG_TASK_PUSH = 1,
     PMG_TASK_PICK_AND_PLACE = 2,
     PMG_TASK_SLIDE = 3,
-    PMG_TASK_BLOCK_STACK = 4
+    PMG_TASK_BLOCK_STACK = 4,
+    PMG_TASK_BLOCK_REARRANGE = 5
 };
 
 enum {
@@ -62,7 +63,7 @@ typedef struct pmg_config {
     int32_t struct_size;
     int32_t task;               /* PMG_TASK_* */
     int32_t num_envs;           /* N: envs simulated by THIS handle (one GPU) */
-    int32_t num_block;          /* block_stack only, 1..5 (P/__init__.py:108) */
+    int32_t num_block;          /* block_stack / block_rearrange only, 1..5 (P/__init__.py:108) */
     int32_t binary_reward;      /* P/__init__.py:4 */
     int32_t joint_control;      /* P/__init__.py:6 */
     int32_t max_episode_steps;  /* gym TimeLimit, P/__init__.py:6,105 */
@@ -72,7 +73,10 @@ typedef struct pmg_config {
     uint64_t seed_base;         /* env i is seeded with seed_base + i*seed_stride */
     uint64_t seed_stride;       /* 0 reproduces the reference (every env seed 0) */
     int32_t env_index_offset;   /* global index of this shard's env 0 (multi-GPU) */
-    int32_t reserved[7];
+    int32_t task_decomposition; /* block_stack: sub-goals, kuka_multi_step_envs.py:89-122 (excludes use_curriculum) */
+    int32_t use_curriculum;     /* block_stack / block_rearrange: kuka_multi_step_base_env.py:121-140 (num_block >= 2) */
+    int32_t num_goals_to_generate; /* curriculum budget, P/__init__.py:11 (default 1e6); 0 = 1e6 */
+    int32_t reserved[4];
 } pmg_config;
 
 typedef struct pmg_dims {
@@ -135,12 +139,28 @@ int pmg_compute_reward_device(pmg_env* env, const float* d_achieved_goal, const 
                               int64_t batch, float* d_reward, uint8_t* d_goal_achieved);
 
 /* Checkpoint / test hooks (no reference equivalent).
- * state: [N, state_dim] float32, layout documented in DESIGN.md. */
+ * state: [N, state_dim] float32, layout documented in DESIGN.md (with use_curriculum the row ends with 16
+ * floats of curriculum state: prob[5] generated[5] goal_step). */
 int pmg_get_state(pmg_env* env, float* state);
 int pmg_set_state(pmg_env* env, const float* state);
 /* Host-injected goal / object poses for seed-parity tests (replaces the RNG
  * draws of _generate_goal for the masked envs).  goals: [N, goal_dim]. */
 int pmg_set_goal(pmg_env* env, const uint8_t* mask, const float* goals);
+
+/* Multi-step task bookkeeping (block_stack / block_rearrange), per env -- the reference keeps one copy per
+ * env object.  The desired goal of these tasks is re-derived from the current block poses at every observation
+ * (kuka_multi_step_base_env.py:309-312): blocks beyond the active level are "already at their goal".
+ *
+ * Replaces: KukaBulletMultiBlockEnv.set_sub_goal (kuka_multi_step_base_env.py:154-177): sub-goal index for
+ * the masked envs (mask NULL = all), -1 = the final goal, as after reset; refreshes desired_goal in the output
+ * buffers.  PMG_E_STATE unless the handle was created with task_decomposition. */
+int pmg_set_sub_goal(pmg_env* env, const uint8_t* mask, int32_t sub_goal_ind);
+/* Replaces: activate_curriculum_update / deactivate_curriculum_update (kuka_multi_step_base_env.py:142-152). */
+int pmg_curriculum_update(pmg_env* env, int32_t enabled);
+/* Curriculum read-out, any pointer may be NULL: level [N] (last_curriculum_level), goal_step [N]
+ * (curriculum_goal_step = level*25 + 50), prob [N, num_block] (curriculum_prob), generated [N, num_block]
+ * (num_generated_goals_per_curriculum). */
+int pmg_curriculum_read(pmg_env* env, int32_t* level, int32_t* goal_step, float* prob, float* generated);
 
 /* Multi-GPU (no reference equivalent): one handle per
  * rank; the only exchange is an RCCL all-gather of PMG_BUF_PACKED. */

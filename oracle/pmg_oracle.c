@@ -1211,9 +1211,13 @@ typedef struct {
     real grip_target;
     int arm_enabled;
     int elapsed, reset_count;
-    real goal[16];
+    real goal[16];           /* static targets: stack = per block, rearrange = per target slot */
     int order[NBMAX];
     real base_target[3];
+    int level;               /* active curriculum level / sub-goal index (nb-1 = the full goal) */
+    int moved;               /* rearrange curriculum: bit i = block i has a target */
+    double cur_prob[NBMAX], cur_count[NBMAX]; /* curriculum_prob, num_generated_goals_per_curriculum */
+    int cur_goal_step;       /* curriculum_goal_step */
     Block blk[NBMAX];
     mt19937 rng;
 } World;
@@ -1227,6 +1231,9 @@ struct pmgo_env {
     real ee_lo[3], ee_hi[3];
     real table_c[3], table_h[3], table_mu;
     real obj_z;
+    int multi;                   /* multi-block observation layout (block_stack / block_rearrange) */
+    int curriculum_update;       /* activate_curriculum_update() */
+    double goals_per_curriculum; /* num_goals_to_generate // num_curriculum */
     int obj_cyl;                 /* the single free object is the slide puck (cylinder) */
     real obj_inertia[3], obj_half[3], obj_mu; /* principal inertia, half extents (cyl: r, r, h/2), friction */
     World* w;
@@ -1596,8 +1603,9 @@ static void env_constants(pmgo_env* e)
     e->grasping = (t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
     e->has_obj = (t != PMG_TASK_REACH);
     e->in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
-    e->start_on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE);
-    e->nb = t == PMG_TASK_REACH ? 0 : (t == PMG_TASK_BLOCK_STACK ? c->num_block : 1);
+    e->start_on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE || t == PMG_TASK_BLOCK_REARRANGE); /* kuka_multi_step_envs.py:169 */
+    e->multi = (t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_BLOCK_REARRANGE);
+    e->nb = t == PMG_TASK_REACH ? 0 : (e->multi ? c->num_block : 1);
     real obj_range = t == PMG_TASK_SLIDE ? (real)0.1 : (real)0.15, tgt_range = t == PMG_TASK_SLIDE ? (real)0.2 : (real)0.15;
     /* kuka.py:35-51 */
     v3set(e->tip_init, (real)-0.52, 0, (real)0.25);
@@ -1702,7 +1710,64 @@ static void stack_goal_from_order(const pmgo_env* e, World* w)
         w->goal[3 * b + 2] = (real)0.175 + (real)0.03 * (real)s;
     }
 }
-static void task_reset_stack(const pmgo_env* e, World* w)
+/* [NUMPY] RandomState.choice(n, p=p), size None: cdf = p.cumsum(); cdf /= cdf[-1];
+ * idx = cdf.searchsorted(random_sample(), side='right')  (tests/golden/curriculum.json pins it) */
+static int mt_choice_p(mt19937* rng, const double* p, int n)
+{
+    double cdf[NBMAX], acc = 0;
+    for (int i = 0; i < n; i++) { acc += p[i]; cdf[i] = acc; }
+    for (int i = 0; i < n; i++) cdf[i] /= cdf[n - 1];
+    double u = mt_double(rng);
+    int idx = 0;
+    while (idx < n && cdf[idx] <= u) idx++;
+    return idx;
+}
+
+/* _update_curriculum_prob: kuka_multi_step_base_env.py:350-379 */
+static void update_curriculum_prob(const pmgo_env* e, World* w)
+{
+    int n = e->nb;
+    int fin[NBMAX], half[NBMAX];
+    for (int i = 0; i < n; i++) {
+        fin[i] = w->cur_count[i] >= e->goals_per_curriculum;
+        half[i] = w->cur_count[i] >= e->goals_per_curriculum / 2;
+        if (fin[i]) w->cur_prob[i] = 0.0;
+    }
+    if (half[0] && !fin[0]) { w->cur_prob[0] = 0.5; w->cur_prob[1] = 0.5; }
+    for (int i = 1; i < n - 1; i++)
+        if (fin[i - 1] && !fin[i]) {
+            if (half[i]) { w->cur_prob[i] = 0.5; w->cur_prob[i + 1] = 0.5; }
+            else w->cur_prob[i] = 1.0;
+        }
+    if (fin[n - 2]) w->cur_prob[n - 1] = 1.0;
+}
+
+/* curriculum level draw shared by both tasks: kuka_multi_step_envs.py:125-134, 199-213 */
+static void curriculum_new_target(const pmgo_env* e, World* w)
+{
+    int level = mt_choice_p(&w->rng, w->cur_prob, e->nb);
+    w->level = level;
+    w->cur_goal_step = level * 25 + 50;
+    if (e->cfg.task == PMG_TASK_BLOCK_REARRANGE) {
+        /* np_random.choice(arange(nb), size=level+1, replace=False) == permutation(nb)[:level+1] (sorted after) */
+        int perm[NBMAX];
+        for (int i = 0; i < e->nb; i++) perm[i] = i;
+        for (int i = e->nb - 1; i >= 1; i--) {
+            uint32_t j = mt_interval(&w->rng, (uint32_t)i);
+            int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+        }
+        w->moved = 0;
+        for (int i = 0; i <= level; i++) w->moved |= 1 << perm[i];
+    }
+    if (e->curriculum_update) {
+        w->cur_count[level] += 1;
+        update_curriculum_prob(e, w);
+    }
+}
+
+/* multi-block reset: kuka_multi_step_base_env.py:221-250 + kuka_multi_step_envs.py:34-87 (stack),
+ * :174-197 (rearrange) */
+static void task_reset_multi(const pmgo_env* e, World* w)
 {
     double bp[NBMAX][2];
     for (int b = 0; b < e->nb; b++) {
@@ -1718,26 +1783,66 @@ static void task_reset_stack(const pmgo_env* e, World* w)
     }
     for (int b = 0; b < e->nb; b++) set_block(&w->blk[b], (real)bp[b][0], (real)bp[b][1], (real)0.175);
     for (int b = 0; b < NBMAX; b++) w->order[b] = b;
-    if (e->cfg.random_order)
-        for (int i = e->nb - 1; i >= 1; i--) {
-            uint32_t j = mt_interval(&w->rng, (uint32_t)i);
-            int t = w->order[i]; w->order[i] = w->order[j]; w->order[j] = t;
+    w->level = e->nb - 1;
+    w->moved = (1 << e->nb) - 1;
+    if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
+        if (e->cfg.random_order)
+            for (int i = e->nb - 1; i >= 1; i--) {
+                uint32_t j = mt_interval(&w->rng, (uint32_t)i);
+                int t = w->order[i]; w->order[i] = w->order[j]; w->order[j] = t;
+            }
+        for (;;) {
+            double x = mt_uniform(&w->rng, e->tgt_lo[0], e->tgt_hi[0]);
+            double y = mt_uniform(&w->rng, e->tgt_lo[1], e->tgt_hi[1]);
+            int ok = 1;
+            for (int c = 0; c < e->nb; c++)
+                if (!(norm2d(x - bp[c][0], y - bp[c][1]) > 0.08)) ok = 0;
+            if (ok) { v3set(w->base_target, (real)x, (real)y, (real)0.175); break; }
         }
-    for (;;) {
-        double x = mt_uniform(&w->rng, e->tgt_lo[0], e->tgt_hi[0]);
-        double y = mt_uniform(&w->rng, e->tgt_lo[1], e->tgt_hi[1]);
-        int ok = 1;
-        for (int c = 0; c < e->nb; c++)
-            if (!(norm2d(x - bp[c][0], y - bp[c][1]) > 0.08)) ok = 0;
-        if (ok) { v3set(w->base_target, (real)x, (real)y, (real)0.175); break; }
+        stack_goal_from_order(e, w);
+    } else {
+        double tp[NBMAX][2];
+        for (int t = 0; t < e->nb; t++)
+            for (;;) {
+                double x = mt_uniform(&w->rng, e->tgt_lo[0], e->tgt_hi[0]);
+                double y = mt_uniform(&w->rng, e->tgt_lo[1], e->tgt_hi[1]);
+                int ok = 1;
+                for (int c = 0; c < t; c++)
+                    if (!(norm2d(x - tp[c][0], y - tp[c][1]) > 0.06)) ok = 0;
+                for (int c = 0; c < e->nb; c++)
+                    if (!(norm2d(x - bp[c][0], y - bp[c][1]) > 0.06)) ok = 0;
+                if (ok) { tp[t][0] = x; tp[t][1] = y; break; }
+            }
+        for (int t = 0; t < e->nb; t++) { w->goal[3 * t] = (real)tp[t][0]; w->goal[3 * t + 1] = (real)tp[t][1]; w->goal[3 * t + 2] = (real)0.175; }
     }
-    stack_goal_from_order(e, w);
+    if (e->cfg.use_curriculum) curriculum_new_target(e, w);
+}
+
+/* the desired goal as _get_obs re-derives it from the current block poses every observation
+ * (kuka_multi_step_base_env.py:309-312 -> _generate_goal(new_target=False) / set_sub_goal) */
+static void effective_goal(const pmgo_env* e, const World* w, double* dg)
+{
+    int G = e->dims.goal_dim;
+    if (!e->multi) { for (int g = 0; g < G; g++) dg[g] = w->goal[g]; return; }
+    if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
+        for (int s_ = 0; s_ < e->nb; s_++) {
+            int b = w->order[s_];
+            for (int a = 0; a < 3; a++) dg[3 * b + a] = s_ <= w->level ? w->goal[3 * b + a] : w->blk[b].pos[a];
+        }
+    } else {
+        int k = 0;
+        for (int b = 0; b < e->nb; b++) {
+            int mv = (w->moved >> b) & 1;
+            for (int a = 0; a < 3; a++) dg[3 * b + a] = mv ? w->goal[3 * k + a] : w->blk[b].pos[a];
+            k += mv;
+        }
+    }
 }
 
 static void env_reset_one(const pmgo_env* e, World* w)
 {
     robot_reset(e, w);
-    if (e->cfg.task == PMG_TASK_BLOCK_STACK) task_reset_stack(e, w);
+    if (e->multi) task_reset_multi(e, w);
     else task_reset_single(e, w);
     w->elapsed = 0;
     w->reset_count++;
@@ -1766,7 +1871,7 @@ static void env_obs(const pmgo_env* e, const World* w, float* obs, float* pol, f
     double o[160], p[64];
     int no = 0, np = 0;
     if (jo) for (int d = 0; d < 7; d++) { o[no++] = w->q[d]; p[np++] = w->q[d]; }
-    if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
+    if (e->multi) {
         for (int a = 0; a < 3; a++) { o[no++] = tip[a]; p[np++] = tip[a]; }
         o[no++] = closeness; p[np++] = closeness;
         for (int a = 0; a < 3; a++) o[no++] = tv[a];
@@ -1802,7 +1907,11 @@ static void env_obs(const pmgo_env* e, const World* w, float* obs, float* pol, f
     }
     if (obs) for (int i = 0; i < no; i++) obs[i] = (float)o[i];
     if (pol) for (int i = 0; i < np; i++) pol[i] = (float)p[i];
-    if (dg) for (int i = 0; i < G; i++) dg[i] = (float)w->goal[i];
+    if (dg) {
+        double d64[16];
+        effective_goal(e, w, d64);
+        for (int i = 0; i < G; i++) dg[i] = (float)d64[i];
+    }
 }
 
 /* reward: kuka_single_step_base_env.py:237-244 */
@@ -1859,13 +1968,20 @@ static int fill_dims(const pmg_config* c, pmg_dims* d)
     case PMG_TASK_PICK_AND_PLACE:
         d->action_dim = jo ? 8 : 4; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
     case PMG_TASK_BLOCK_STACK:
+    case PMG_TASK_BLOCK_REARRANGE: {
         if (c->num_block < 1 || c->num_block > NBMAX) return -1;
-        d->action_dim = jo ? 8 : 4; d->observation_dim = 8 + 16 * c->num_block + jo;
+        if (c->use_curriculum && (c->num_block < 2 || c->task_decomposition)) return -1; /* kuka_multi_step_base_env.py:123,131 */
+        if (c->task_decomposition && c->task != PMG_TASK_BLOCK_STACK) return -1;          /* kuka_multi_step_envs.py:159 */
+        int gr = c->task == PMG_TASK_BLOCK_STACK;
+        d->action_dim = (jo ? 7 : 3) + gr; d->observation_dim = 8 + 16 * c->num_block + jo;
         d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; break;
+    }
     default: return -1;
     }
-    int nb = c->task == PMG_TASK_REACH ? 0 : (c->task == PMG_TASK_BLOCK_STACK ? c->num_block : 1);
-    d->state_dim = 64 + 13 * nb;
+    if (c->task != PMG_TASK_BLOCK_STACK && c->task != PMG_TASK_BLOCK_REARRANGE && (c->use_curriculum || c->task_decomposition)) return -1;
+    int multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE;
+    int nb = c->task == PMG_TASK_REACH ? 0 : (multi ? c->num_block : 1);
+    d->state_dim = 64 + 13 * nb + (c->use_curriculum ? 16 : 0);
     d->packed_dim = d->observation_dim + d->policy_state_dim + 2 * d->goal_dim + 3;
     return 0;
 }
@@ -1890,6 +2006,13 @@ int pmgo_create(const pmg_config* cfg, pmgo_env** out)
         World* w = &e->w[i];
         for (int d = 0; d < 7; d++) w->rest_pose[d] = (real)REST_POSE0[d];
         for (int b = 0; b < NBMAX; b++) set_block(&w->blk[b], 0, 0, -3);
+        w->cur_prob[0] = 1.0;              /* kuka_multi_step_base_env.py:133 */
+        w->cur_goal_step = 50;
+        w->level = 0;
+    }
+    {
+        double total = cfg->num_goals_to_generate > 0 ? (double)cfg->num_goals_to_generate : 1e6;
+        e->goals_per_curriculum = e->nb > 0 ? floor(total / e->nb) : total;   /* :139 */
     }
     *out = e;
     pmgo_seed(e, cfg->seed_base, cfg->seed_stride);
@@ -1947,7 +2070,7 @@ int pmgo_step(pmgo_env* e, const float* actions, float* obs, float* pol, float* 
         env_obs(e, w, obs ? obs + (size_t)i * dm->observation_dim : NULL, pol ? pol + (size_t)i * dm->policy_state_dim : NULL, agl, dgl);
         /* reward from the double-precision goals (the reference's obs are float64) */
         double a64[16], d64[16];
-        for (int g = 0; g < dm->goal_dim; g++) d64[g] = w->goal[g];
+        effective_goal(e, w, d64);
         if (e->cfg.task == PMG_TASK_REACH) {
             Kin k; kinematics(w->q, &k);
             for (int g = 0; g < 3; g++) a64[g] = k.p[PMG_BL_TIP][g];
@@ -1998,6 +2121,12 @@ int pmgo_get_state(pmgo_env* e, float* state)
         for (int b = 0; b < NBMAX; b++) s[40 + b] = (float)w->order[b];
         for (int a = 0; a < 3; a++) s[45 + a] = (float)w->base_target[a];
         for (int g = 0; g < 15; g++) s[48 + g] = (float)w->goal[g];
+        s[39] = (float)w->level; s[63] = (float)w->moved;
+        if (e->cfg.use_curriculum) {
+            float* cs = s + 64 + 13 * e->nb;
+            for (int b = 0; b < NBMAX; b++) { cs[b] = (float)w->cur_prob[b]; cs[5 + b] = (float)w->cur_count[b]; }
+            cs[10] = (float)w->cur_goal_step;
+        }
         for (int b = 0; b < e->nb; b++) {
             const Block* bl = &w->blk[b];
             float* o = s + 64 + 13 * b;
@@ -2021,6 +2150,12 @@ int pmgo_set_state(pmgo_env* e, const float* state)
         for (int b = 0; b < NBMAX; b++) w->order[b] = (int)s[40 + b];
         for (int a = 0; a < 3; a++) w->base_target[a] = s[45 + a];
         for (int g = 0; g < 15; g++) w->goal[g] = s[48 + g];
+        w->level = (int)s[39]; w->moved = (int)s[63];
+        if (e->cfg.use_curriculum) {
+            const float* cs = s + 64 + 13 * e->nb;
+            for (int b = 0; b < NBMAX; b++) { w->cur_prob[b] = cs[b]; w->cur_count[b] = cs[5 + b]; }
+            w->cur_goal_step = (int)cs[10];
+        }
         for (int b = 0; b < e->nb; b++) {
             Block* bl = &w->blk[b];
             const float* o = s + 64 + 13 * b;
@@ -2036,5 +2171,35 @@ int pmgo_set_goal(pmgo_env* e, const uint8_t* mask, const float* goals)
     for (int i = 0; i < e->cfg.num_envs; i++)
         if (!mask || mask[i])
             for (int g = 0; g < G; g++) e->w[i].goal[g] = goals[(size_t)i * G + g];
+    return PMG_OK;
+}
+
+/* set_sub_goal: kuka_multi_step_base_env.py:154-177 */
+int pmgo_set_sub_goal(pmgo_env* e, const uint8_t* mask, int32_t ind)
+{
+    if (!e->cfg.task_decomposition) { snprintf(e->err, sizeof(e->err), "pmgo_set_sub_goal: task_decomposition is off"); return PMG_E_STATE; }
+    if (ind < -1 || ind >= e->nb) { snprintf(e->err, sizeof(e->err), "pmgo_set_sub_goal: index %d out of range", ind); return PMG_E_INVALID; }
+    for (int i = 0; i < e->cfg.num_envs; i++)
+        if (!mask || mask[i]) e->w[i].level = ind < 0 ? e->nb - 1 : ind;
+    return PMG_OK;
+}
+int pmgo_curriculum_update(pmgo_env* e, int32_t enabled)
+{
+    if (!e->cfg.use_curriculum) { snprintf(e->err, sizeof(e->err), "pmgo_curriculum_update: use_curriculum is off"); return PMG_E_STATE; }
+    e->curriculum_update = enabled != 0;
+    return PMG_OK;
+}
+int pmgo_curriculum_read(pmgo_env* e, int32_t* level, int32_t* goal_step, float* prob, float* generated)
+{
+    if (!e->cfg.use_curriculum) { snprintf(e->err, sizeof(e->err), "pmgo_curriculum_read: use_curriculum is off"); return PMG_E_STATE; }
+    for (int i = 0; i < e->cfg.num_envs; i++) {
+        const World* w = &e->w[i];
+        if (level) level[i] = w->level;
+        if (goal_step) goal_step[i] = w->cur_goal_step;
+        for (int b = 0; b < e->nb; b++) {
+            if (prob) prob[(size_t)i * e->nb + b] = (float)w->cur_prob[b];
+            if (generated) generated[(size_t)i * e->nb + b] = (float)w->cur_count[b];
+        }
+    }
     return PMG_OK;
 }

@@ -42,6 +42,9 @@ int pmgo_compute_reward(pmgo_env* env, const float* achieved_goal, const float* 
 int pmgo_get_state(pmgo_env* env, float* state);
 int pmgo_set_state(pmgo_env* env, const float* state);
 int pmgo_set_goal(pmgo_env* env, const uint8_t* mask, const float* goals);
+int pmgo_set_sub_goal(pmgo_env* env, const uint8_t* mask, int32_t sub_goal_ind);
+int pmgo_curriculum_update(pmgo_env* env, int32_t enabled);
+int pmgo_curriculum_read(pmgo_env* env, int32_t* level, int32_t* goal_step, float* prob, float* generated);
 int pmgo_set_threads(pmgo_env* env, int nthreads);   /* OpenMP threads for the env loop */
 
 /* ---- probes used by the unit tests (double precision, single env) ---- */

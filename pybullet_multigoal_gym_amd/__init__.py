@@ -13,7 +13,7 @@ _TASKS = ['push', 'reach', 'slide', 'pick_and_place',
           'block_stack', 'block_rearrange', 'chest_pick_and_place', 'chest_push',
           'primitive_push_assemble', 'primitive_push_reach', 'insertion']
 _GRIPPERS = ['robotiq85', 'parallel_jaw']
-_ACCELERATED = ['reach', 'push', 'slide', 'pick_and_place', 'block_stack']
+_ACCELERATED = ['reach', 'push', 'slide', 'pick_and_place', 'block_stack', 'block_rearrange']
 
 
 def make_env(task='reach', gripper='parallel_jaw', num_block=5, render=False, binary_reward=True,
@@ -48,13 +48,14 @@ def make_env(task='reach', gripper='parallel_jaw', num_block=5, render=False, bi
         unsupported('state_noise')
     if grip_informed_goal:
         unsupported('grip_informed_goal')
-    if task_decomposition:
-        unsupported('task_decomposition')
-    if use_curriculum:
-        unsupported('use_curriculum')
-    if task == 'block_stack':
+    if task in ('block_stack', 'block_rearrange'):
         assert num_block <= 5, "only support up to 5 blocks"
+        if task == 'block_rearrange':   # kuka_multi_step_envs.py:158-159
+            assert not task_decomposition, 'Block rearranging task does not support task decomposition.'
+    elif task_decomposition or use_curriculum:
+        unsupported('task_decomposition / use_curriculum outside block_stack and block_rearrange')
     return KukaVecEnv(task=task, num_envs=num_envs, binary_reward=binary_reward, joint_control=joint_control,
                       max_episode_steps=max_episode_steps, distance_threshold=distance_threshold, num_block=num_block,
                       seed=seed, seed_stride=seed_stride, device=device, env_index_offset=env_index_offset,
-                      dtype=dtype, _library=_library)
+                      dtype=dtype, task_decomposition=task_decomposition, use_curriculum=use_curriculum,
+                      num_goals_to_generate=num_goals_to_generate, _library=_library)

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, 'csrc', 'libpmg_hip.so')
 
-TASK_IDS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4}
+TASK_IDS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4, 'block_rearrange': 5}
 PMG_BUF_PACKED = 7
 PMG_BUF_STATE = 8
 
@@ -21,7 +21,8 @@ class PmgConfig(C.Structure):
                 ('binary_reward', C.c_int32), ('joint_control', C.c_int32), ('max_episode_steps', C.c_int32),
                 ('device', C.c_int32), ('distance_threshold', C.c_float), ('random_order', C.c_int32),
                 ('seed_base', C.c_uint64), ('seed_stride', C.c_uint64), ('env_index_offset', C.c_int32),
-                ('reserved', C.c_int32 * 7)]
+                ('task_decomposition', C.c_int32), ('use_curriculum', C.c_int32), ('num_goals_to_generate', C.c_int32),
+                ('reserved', C.c_int32 * 4)]
 
 
 class PmgDims(C.Structure):
@@ -45,7 +46,8 @@ class PmgLibrary:
                'pmg_reset_device', 'pmg_step_device', 'pmg_device_ptr', 'pmg_stream', 'pmg_sync', 'pmg_read_outputs',
                'pmg_compute_reward', 'pmg_compute_reward_device', 'pmg_get_state', 'pmg_set_state', 'pmg_set_goal',
                'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_read',
-               'pmg_device_alloc', 'pmg_device_free', 'pmg_upload', 'pmg_download']
+               'pmg_device_alloc', 'pmg_device_free', 'pmg_upload', 'pmg_download',
+               'pmg_set_sub_goal', 'pmg_curriculum_update', 'pmg_curriculum_read']
 
     def __init__(self, path=None):
         self.path = path or DEFAULT_LIBRARY
@@ -171,6 +173,21 @@ class PmgHandle:
         goals = np.ascontiguousarray(goals, np.float32).reshape(self.N, self.dims.goal_dim)
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.N)
         self._check(self.L.lib.pmg_set_goal(self.h, _p(m), _p(goals)))
+
+    # -- multi-step task bookkeeping ----------------------------------------
+    def set_sub_goal(self, sub_goal_ind, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8).reshape(self.N)
+        self._check(self.L.lib.pmg_set_sub_goal(self.h, _p(m), C.c_int32(int(sub_goal_ind))))
+
+    def curriculum_update(self, enabled):
+        self._check(self.L.lib.pmg_curriculum_update(self.h, C.c_int32(int(bool(enabled)))))
+
+    def curriculum_read(self):
+        nb = self.cfg.num_block
+        level, goal_step = np.empty(self.N, np.int32), np.empty(self.N, np.int32)
+        prob, generated = np.empty((self.N, nb), np.float32), np.empty((self.N, nb), np.float32)
+        self._check(self.L.lib.pmg_curriculum_read(self.h, _p(level), _p(goal_step), _p(prob), _p(generated)))
+        return level, goal_step, prob, generated
 
     # -- device-resident calls --------------------------------------------
     def step_device(self, d_actions_ptr):

@@ -142,14 +142,19 @@ int fill_dims(const pmg_config* c, pmg_dims* d, int* nb_out)
     case PMG_TASK_PUSH: case PMG_TASK_SLIDE: d->action_dim = jo ? 7 : 3; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
     case PMG_TASK_PICK_AND_PLACE: d->action_dim = jo ? 8 : 4; d->observation_dim = 20 + jo; d->policy_state_dim = 7 + jo; d->goal_dim = 3; break;
     case PMG_TASK_BLOCK_STACK:
+    case PMG_TASK_BLOCK_REARRANGE:
         if (c->num_block < 1 || c->num_block > 5) return -1;
-        d->action_dim = jo ? 8 : 4; d->observation_dim = 8 + 16 * c->num_block + jo;
+        if (c->use_curriculum && (c->num_block < 2 || c->task_decomposition)) return -1; /* kuka_multi_step_base_env.py:123,131 */
+        if (c->task_decomposition && c->task != PMG_TASK_BLOCK_STACK) return -1;          /* kuka_multi_step_envs.py:159 */
+        d->action_dim = (jo ? 7 : 3) + (c->task == PMG_TASK_BLOCK_STACK ? 1 : 0); d->observation_dim = 8 + 16 * c->num_block + jo;
         d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; break;
     default: return -1;
     }
-    int nb = c->task == PMG_TASK_REACH ? 0 : (c->task == PMG_TASK_BLOCK_STACK ? c->num_block : 1);
+    bool multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE;
+    if (!multi && (c->use_curriculum || c->task_decomposition)) return -1;
+    int nb = c->task == PMG_TASK_REACH ? 0 : (multi ? c->num_block : 1);
     *nb_out = nb;
-    d->state_dim = 64 + 13 * nb;
+    d->state_dim = 64 + 13 * nb + (c->use_curriculum ? pmg::CURR_DIM : 0);
     d->packed_dim = d->observation_dim + d->policy_state_dim + 2 * d->goal_dim + 3;
     return 0;
 }
@@ -166,10 +171,16 @@ void fill_params(pmg_env* e)
     P.in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
     P.joint_control = c.joint_control; P.binary_reward = c.binary_reward; P.max_steps = c.max_episode_steps;
     P.random_order = c.random_order;
+    P.multi = (t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_BLOCK_REARRANGE);
+    P.curriculum = c.use_curriculum; P.curriculum_update = 0;
+    {
+        double total = c.num_goals_to_generate > 0 ? (double)c.num_goals_to_generate : 1e6;
+        P.goals_per_curriculum = e->nb > 0 ? floor(total / e->nb) : total; /* kuka_multi_step_base_env.py:139 */
+    }
     P.adim = e->dims.action_dim; P.odim = e->dims.observation_dim; P.pdim = e->dims.policy_state_dim;
     P.gdim = e->dims.goal_dim; P.packed = e->dims.packed_dim;
     P.thr = c.distance_threshold;
-    bool on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE);
+    bool on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE || t == PMG_TASK_BLOCK_REARRANGE); /* kuka_multi_step_envs.py:169 */
     double range = 0.15, trange = 0.15;
     if (t == PMG_TASK_SLIDE) { range = 0.1; trange = 0.2; } /* kuka_single_step_base_env.py:66-69 */
     P.tip_init[0] = -0.52; P.tip_init[1] = 0.0; P.tip_init[2] = 0.25;
@@ -277,6 +288,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipMalloc((void**)&e->P.hot, N * pmg::HOT_DIM * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.cold, N * pmg::COLD_DIM * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.goal, N * pmg::GOAL_DIM * sizeof(float)));
+    if (cfg->use_curriculum) CREATE_TRY(hipMalloc((void**)&e->P.curr, N * pmg::CURR_DIM * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.blocks, N * pmg::BLOCK_DIM * (nb ? nb : 1) * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.rng, N * 625 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
@@ -304,6 +316,11 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         }
         CREATE_TRY(hipMemset(e->P.hot, 0, N * pmg::HOT_DIM * sizeof(float)));
         CREATE_TRY(hipMemset(e->P.goal, 0, N * pmg::GOAL_DIM * sizeof(float)));
+        if (e->P.curr) { /* start with the easiest goal as the only possible one (kuka_multi_step_base_env.py:133) */
+            std::vector<float> cs(N * pmg::CURR_DIM, 0.f);
+            for (size_t i = 0; i < N; i++) { cs[i * pmg::CURR_DIM] = 1.f; cs[i * pmg::CURR_DIM + 10] = 50.f; }
+            CREATE_TRY(hipMemcpy(e->P.curr, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         CREATE_TRY(hipMemset(e->P.out, 0, N * dims.packed_dim * sizeof(float)));
     }
     if (upload_seeds(e) != PMG_OK) return bail(PMG_E_DEVICE);
@@ -317,7 +334,7 @@ void pmg_destroy(pmg_env* e)
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
-    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out); (void)hipFree(e->P.sched);
+    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out); (void)hipFree(e->P.sched);
     (void)hipFree(e->d_actions); (void)hipFree(e->d_mask);
     (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
     if (e->h_packed) (void)hipHostFree(e->h_packed);
@@ -488,6 +505,11 @@ int pmg_get_state(pmg_env* e, float* state)
         memcpy(s + 48, &goal[i * pmg::GOAL_DIM], sizeof(float) * pmg::GOAL_DIM);
         if (nbd) memcpy(s + 64, &blk[i * nbd], sizeof(float) * nbd);
     }
+    if (e->P.curr) {
+        std::vector<float> cs(N * pmg::CURR_DIM);
+        HIP_TRY(e, hipMemcpy(cs.data(), e->P.curr, cs.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < N; i++) memcpy(state + i * S + 64 + nbd, &cs[i * pmg::CURR_DIM], sizeof(float) * pmg::CURR_DIM);
+    }
     return PMG_OK;
 }
 
@@ -510,6 +532,11 @@ int pmg_set_state(pmg_env* e, const float* state)
     HIP_TRY(e, hipMemcpy(e->P.cold, cold.data(), cold.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->P.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
     if (nbd) HIP_TRY(e, hipMemcpy(e->P.blocks, blk.data(), N * nbd * sizeof(float), hipMemcpyHostToDevice));
+    if (e->P.curr) {
+        std::vector<float> cs(N * pmg::CURR_DIM);
+        for (size_t i = 0; i < N; i++) memcpy(&cs[i * pmg::CURR_DIM], state + i * S + 64 + nbd, sizeof(float) * pmg::CURR_DIM);
+        HIP_TRY(e, hipMemcpy(e->P.curr, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
     e->ever_reset = true;
     return PMG_OK;
 }
@@ -526,6 +553,52 @@ int pmg_set_goal(pmg_env* e, const uint8_t* mask, const float* goals)
     for (size_t i = 0; i < N; i++)
         if (!mask || mask[i]) memcpy(&goal[i * pmg::GOAL_DIM], goals + i * G, sizeof(float) * G);
     HIP_TRY(e, hipMemcpy(e->P.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
+    return PMG_OK;
+}
+
+int pmg_set_sub_goal(pmg_env* e, const uint8_t* mask, int32_t sub_goal_ind)
+{
+    if (!e) return PMG_E_INVALID;
+    if (!e->cfg.task_decomposition) return fail(e, PMG_E_STATE, "pmg_set_sub_goal: the handle was created without task_decomposition");
+    if (sub_goal_ind < -1 || sub_goal_ind >= e->nb) return fail(e, PMG_E_INVALID, "pmg_set_sub_goal: index %d out of range [-1, %d)", sub_goal_ind, e->nb);
+    if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_set_sub_goal: reset first");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const unsigned char* dm = nullptr;
+    if (mask) {
+        HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, (size_t)e->dims.num_envs, hipMemcpyHostToDevice, e->stream));
+        dm = e->d_mask;
+    }
+    HIP_TRY(e, pmg_launch_sub_goal(e->P, dm, sub_goal_ind < 0 ? e->nb - 1 : sub_goal_ind, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return PMG_OK;
+}
+
+int pmg_curriculum_update(pmg_env* e, int32_t enabled)
+{
+    if (!e) return PMG_E_INVALID;
+    if (!e->cfg.use_curriculum) return fail(e, PMG_E_STATE, "pmg_curriculum_update: the handle was created without use_curriculum");
+    e->P.curriculum_update = enabled != 0;
+    return PMG_OK;
+}
+
+int pmg_curriculum_read(pmg_env* e, int32_t* level, int32_t* goal_step, float* prob, float* generated)
+{
+    if (!e) return PMG_E_INVALID;
+    if (!e->cfg.use_curriculum) return fail(e, PMG_E_STATE, "pmg_curriculum_read: the handle was created without use_curriculum");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    size_t N = (size_t)e->dims.num_envs;
+    std::vector<float> cs(N * pmg::CURR_DIM), cold(N * pmg::COLD_DIM);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(cs.data(), e->P.curr, cs.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(cold.data(), e->P.cold, cold.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < N; i++) {
+        if (level) level[i] = (int32_t)cold[i * pmg::COLD_DIM + 7];
+        if (goal_step) goal_step[i] = (int32_t)cs[i * pmg::CURR_DIM + 10];
+        for (int b = 0; b < e->nb; b++) {
+            if (prob) prob[i * e->nb + b] = cs[i * pmg::CURR_DIM + b];
+            if (generated) generated[i * e->nb + b] = cs[i * pmg::CURR_DIM + 5 + b];
+        }
+    }
     return PMG_OK;
 }
 

@@ -22,6 +22,9 @@ namespace pmg {
 
 struct EnvParams {
     int n_envs, task, nb, grasping, has_obj, joint_control, binary_reward, max_steps, in_air, random_order;
+    int multi;              /* multi-block observation layout: block_stack / block_rearrange */
+    int curriculum, curriculum_update; /* kuka_multi_step_base_env.py:121-152 */
+    double goals_per_curriculum;
     int adim, odim, pdim, gdim, packed;
     float thr;
     float ee_lo[3], ee_hi[3];
@@ -31,7 +34,8 @@ struct EnvParams {
     /* device arrays */
     float* hot;      /* [N, HOT_DIM]  */
     float* cold;     /* [N, COLD_DIM] */
-    float* goal;     /* [N, GOAL_DIM] */
+    float* goal;     /* [N, GOAL_DIM]: static targets (stack: per block; rearrange: per target slot), [15] = moved mask */
+    float* curr;     /* [N, CURR_DIM] curriculum state: prob[5] generated[5] goal_step (NULL without use_curriculum) */
     float* blocks;   /* [N, BLOCK_DIM * nb] */
     unsigned* rng;   /* [N, 625] MT19937 state + index */
     float* out;      /* [N, packed]: obs | policy | ag | dg | reward | goal_achieved | done */
@@ -40,6 +44,33 @@ struct EnvParams {
     long long* prof; /* per-phase wall_clock64 ticks of env 0 */
 #endif
 };
+
+/* ------------------------------------------------------------------ */
+/* component i of the desired goal.  The multi-block tasks re-derive it from the current block poses at
+ * every observation (kuka_multi_step_base_env.py:309-312): a block beyond the active curriculum level /
+ * sub-goal index "is already at its goal".  cold[7] = level, goal[15] = moved-block mask.          */
+constexpr int CURR_DIM = 16;
+__device__ __forceinline__ float effective_goal_at_level(const EnvParams& P, int env, int i, int level)
+{
+    const float* g = P.goal + (size_t)env * GOAL_DIM;
+    if (!P.multi) return g[i];
+    const float* cold = P.cold + (size_t)env * COLD_DIM;
+    const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
+    int b = i / 3, a = i - 3 * b;
+    if (P.task == PMG_TASK_BLOCK_STACK) {
+        int pos = 0;
+        for (int s = 0; s < P.nb; s++) pos = ((int)cold[8 + s] == b) ? s : pos;   /* place of block b in the stack order */
+        return pos <= level ? g[i] : bb[BLOCK_DIM * b + a];
+    }
+    int moved = (int)g[15];
+    if (!((moved >> b) & 1)) return bb[BLOCK_DIM * b + a];
+    int kth = __popc((unsigned)moved & ((1u << b) - 1u));                        /* the k-th moved block takes target k */
+    return g[3 * kth + a];
+}
+__device__ __forceinline__ float effective_goal(const EnvParams& P, int env, int i)
+{
+    return effective_goal_at_level(P, env, i, P.multi ? (int)P.cold[(size_t)env * COLD_DIM + 7] : 0);
+}
 
 /* ------------------------------------------------------------------ */
 /* observation / reward pack                                           */
@@ -93,7 +124,7 @@ __device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const
     float agv[3] = {tip[0], tip[1], tip[2]};
     if (P.task == PMG_TASK_REACH) {
         if (l < 3) { float x = l == 0 ? tip[0] : (l == 1 ? tip[1] : tip[2]); obs[jo + l] = x; pol[jo + l] = x; ag[l] = x; }
-    } else if (P.task != PMG_TASK_BLOCK_STACK) {
+    } else if (!P.multi) {
         const float* b = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
         float bp[3] = {b[0], b[1], b[2]}, bv[3] = {b[7], b[8], b[9]}, bw[3] = {b[10], b[11], b[12]};
         if (l == 0) {
@@ -140,17 +171,19 @@ __device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const
         }
     }
     wv::lds_sync();
-    if (P.task == PMG_TASK_BLOCK_STACK) {
+    if (P.multi) {
         for (int i = l; i < P.odim; i += 64) obs[i] = fminf(fmaxf(obs[i], -5.f), 5.f);
         for (int i = l; i < P.pdim; i += 64) pol[i] = fminf(fmaxf(pol[i], -5.f), 5.f);
     }
-    if (l < P.gdim) dg[l] = g[l];
+    float dgl = l < P.gdim ? effective_goal(P, env, l) : 0.f;
+    if (l < P.gdim) dg[l] = dgl;
     if (with_reward) {
         /* _compute_reward: d = ||ag - dg||, binary -(d > thr) as float32 or dense -d */
         float dd = 0.f;
-        if (P.task == PMG_TASK_BLOCK_STACK) {
+        if (P.multi) {
             const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-            for (int i = 0; i < P.gdim; i++) { float e = bb[BLOCK_DIM * (i / 3) + i % 3] - g[i]; dd += e * e; }
+            float e = l < P.gdim ? bb[BLOCK_DIM * (l / 3) + l % 3] - dgl : 0.f;
+            dd = wv::sum_row0(e * e);
         } else {
 #pragma unroll
             for (int a = 0; a < 3; a++) { float e = agv[a] - g[a]; dd += e * e; }
@@ -533,7 +566,7 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
     float* g = P.goal + (size_t)env * GOAL_DIM;
     float* cold = P.cold + (size_t)env * COLD_DIM;
     float* blk = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-    if (P.task != PMG_TASK_BLOCK_STACK) {
+    if (!P.multi) {
         double center[3] = {P.tip_init[0], P.tip_init[1], P.tip_init[2]};
         if (P.has_obj) {
             double ox = P.tip_init[0], oy = P.tip_init[1];
@@ -575,35 +608,95 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
                 if (ok) { bp[b][0] = x; bp[b][1] = y; break; }
             }
         }
-        int order[5] = {0, 1, 2, 3, 4};
-        if (P.random_order)
-            for (int i = P.nb - 1; i >= 1; i--) {
-                unsigned j = mt_interval(mt, (unsigned)i);
-                int t = order[i]; order[i] = order[j]; order[j] = t;
-            }
-        double bx, by;
-        for (;;) {
-            bx = mt_uniform(mt, P.tgt_lo[0], P.tgt_hi[0]);
-            by = mt_uniform(mt, P.tgt_lo[1], P.tgt_hi[1]);
-            bool ok = true;
-            for (int cc = 0; cc < P.nb; cc++) {
-                double dx = bx - bp[cc][0], dy = by - bp[cc][1];
-                if (!(sqrt(dx * dx + dy * dy) > 0.08)) ok = false;
-            }
-            if (ok) break;
-        }
         for (int b = 0; b < P.nb; b++) {
             float* o = blk + BLOCK_DIM * b;
             o[0] = (float)bp[b][0]; o[1] = (float)bp[b][1]; o[2] = 0.175f;
             o[3] = 0.f; o[4] = 0.f; o[5] = 0.f; o[6] = 1.f;
             for (int a = 7; a < 13; a++) o[a] = 0.f;
         }
-        for (int b = 0; b < 5; b++) cold[8 + b] = (float)order[b];
-        cold[13] = (float)bx; cold[14] = (float)by; cold[15] = 0.175f;
-        for (int s = 0; s < P.nb; s++) {
-            int b = order[s];
-            g[3 * b] = (float)bx; g[3 * b + 1] = (float)by; g[3 * b + 2] = 0.175f + 0.03f * (float)s;
+        int order[5] = {0, 1, 2, 3, 4};
+        int level = P.nb - 1, moved = (1 << P.nb) - 1;
+        if (P.task == PMG_TASK_BLOCK_STACK) {
+            if (P.random_order)
+                for (int i = P.nb - 1; i >= 1; i--) {
+                    unsigned j = mt_interval(mt, (unsigned)i);
+                    int t = order[i]; order[i] = order[j]; order[j] = t;
+                }
+            double bx, by;
+            for (;;) {
+                bx = mt_uniform(mt, P.tgt_lo[0], P.tgt_hi[0]);
+                by = mt_uniform(mt, P.tgt_lo[1], P.tgt_hi[1]);
+                bool ok = true;
+                for (int cc = 0; cc < P.nb; cc++) {
+                    double dx = bx - bp[cc][0], dy = by - bp[cc][1];
+                    if (!(sqrt(dx * dx + dy * dy) > 0.08)) ok = false;
+                }
+                if (ok) break;
+            }
+            cold[13] = (float)bx; cold[14] = (float)by; cold[15] = 0.175f;
+            for (int s = 0; s < P.nb; s++) {
+                int b = order[s];
+                g[3 * b] = (float)bx; g[3 * b + 1] = (float)by; g[3 * b + 2] = 0.175f + 0.03f * (float)s;
+            }
+        } else { /* block_rearrange: one table target per block, clear of targets and blocks (kuka_multi_step_envs.py:174-190) */
+            double tp[5][2];
+            for (int t = 0; t < P.nb; t++)
+                for (;;) {
+                    double x = mt_uniform(mt, P.tgt_lo[0], P.tgt_hi[0]);
+                    double y = mt_uniform(mt, P.tgt_lo[1], P.tgt_hi[1]);
+                    bool ok = true;
+                    for (int cc = 0; cc < t; cc++) {
+                        double dx = x - tp[cc][0], dy = y - tp[cc][1];
+                        if (!(sqrt(dx * dx + dy * dy) > 0.06)) ok = false;
+                    }
+                    for (int cc = 0; cc < P.nb; cc++) {
+                        double dx = x - bp[cc][0], dy = y - bp[cc][1];
+                        if (!(sqrt(dx * dx + dy * dy) > 0.06)) ok = false;
+                    }
+                    if (ok) { tp[t][0] = x; tp[t][1] = y; break; }
+                }
+            for (int t = 0; t < P.nb; t++) { g[3 * t] = (float)tp[t][0]; g[3 * t + 1] = (float)tp[t][1]; g[3 * t + 2] = 0.175f; }
         }
+        if (P.curriculum) {
+            /* level = np_random.choice(num_curriculum, p=curriculum_prob): normalised cdf, one double draw,
+             * searchsorted(side='right')  (kuka_multi_step_envs.py:128, 202) */
+            float* cs = P.curr + (size_t)env * CURR_DIM;
+            double cdf[5], acc = 0.0;
+            for (int i = 0; i < P.nb; i++) { acc += (double)cs[i]; cdf[i] = acc; }
+            double u = mt_uniform(mt, 0.0, 1.0);
+            level = 0;
+            while (level < P.nb && cdf[level] / acc <= u) level++;
+            if (level > P.nb - 1) level = P.nb - 1;
+            cs[10] = (float)(level * 25 + 50);
+            if (P.task == PMG_TASK_BLOCK_REARRANGE) { /* choice(arange(nb), size=level+1, replace=False) = permutation(nb)[:level+1] */
+                int perm[5] = {0, 1, 2, 3, 4};
+                for (int i = P.nb - 1; i >= 1; i--) {
+                    unsigned j = mt_interval(mt, (unsigned)i);
+                    int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+                }
+                moved = 0;
+                for (int i = 0; i <= level; i++) moved |= 1 << perm[i];
+            }
+            if (P.curriculum_update) { /* _update_curriculum_prob: kuka_multi_step_base_env.py:350-379 */
+                cs[5 + level] += 1.f;
+                bool fin[5], half[5];
+                for (int i = 0; i < P.nb; i++) {
+                    fin[i] = (double)cs[5 + i] >= P.goals_per_curriculum;
+                    half[i] = (double)cs[5 + i] >= P.goals_per_curriculum / 2;
+                    if (fin[i]) cs[i] = 0.f;
+                }
+                if (half[0] && !fin[0]) { cs[0] = 0.5f; cs[1] = 0.5f; }
+                for (int i = 1; i < P.nb - 1; i++)
+                    if (fin[i - 1] && !fin[i]) {
+                        if (half[i]) { cs[i] = 0.5f; cs[i + 1] = 0.5f; }
+                        else cs[i] = 1.f;
+                    }
+                if (fin[P.nb - 2]) cs[P.nb - 1] = 1.f;
+            }
+        }
+        for (int b = 0; b < 5; b++) cold[8 + b] = (float)order[b];
+        cold[7] = (float)level;
+        g[15] = (float)moved;
     }
 }
 

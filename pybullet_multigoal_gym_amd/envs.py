@@ -25,7 +25,8 @@ from . import spaces
 from ._lib import PmgHandle, TASK_IDS, default_library
 
 TASK_CLASS_NAMES = {'reach': 'KukaReachEnv', 'push': 'KukaPushEnv', 'pick_and_place': 'KukaPickAndPlaceEnv',
-                    'slide': 'KukaSlideEnv', 'block_stack': 'KukaBlockStackEnv'}
+                    'slide': 'KukaSlideEnv', 'block_stack': 'KukaBlockStackEnv',
+                    'block_rearrange': 'KukaBlockRearrangeEnv'}
 
 
 class KukaVecEnv:
@@ -35,7 +36,8 @@ class KukaVecEnv:
 
     def __init__(self, task='reach', num_envs=None, binary_reward=True, joint_control=False, max_episode_steps=50,
                  distance_threshold=0.05, num_block=5, random_order=True, seed=0, seed_stride=1, device=0,
-                 env_index_offset=0, dtype=np.float32, _library=None):
+                 env_index_offset=0, dtype=np.float32, task_decomposition=False, use_curriculum=False,
+                 num_goals_to_generate=1e6, _library=None):
         if task not in TASK_IDS:
             raise ValueError('invalid task name: {}, only support: {}'.format(task, sorted(TASK_IDS)))
         self.task = task
@@ -46,6 +48,18 @@ class KukaVecEnv:
         self.distance_threshold = float(distance_threshold)
         self._max_episode_steps = int(max_episode_steps)
         self.num_block = int(num_block)
+        self.task_decomposition = bool(task_decomposition)
+        self.curriculum = bool(use_curriculum)
+        multi = task in ('block_stack', 'block_rearrange')
+        if self.task_decomposition:   # kuka_multi_step_base_env.py:123, kuka_multi_step_envs.py:159
+            assert not self.curriculum, 'if using task decomposition, curriculum should be False, vice versa'
+            assert task == 'block_stack', 'task decomposition is accelerated for block_stack only'
+        if self.curriculum:
+            assert multi, 'curriculum is a block_stack / block_rearrange option'
+            assert self.num_block >= 2, 'the curriculum schedule needs at least two blocks'
+            warnings.warn("You will need to call env.activate_curriculum_update() before your training phase, "
+                          "and env.deactivate_curriculum_update() before your evaluation phase.")
+        self.curriculum_update = False
         self.dtype = np.dtype(dtype)
         self._seed_stride = int(seed_stride)
         self.handle = PmgHandle(_library or default_library(), task=TASK_IDS[task], num_envs=self.num_envs,
@@ -53,7 +67,8 @@ class KukaVecEnv:
                                 joint_control=int(self.joint_control), max_episode_steps=self._max_episode_steps,
                                 device=int(device), distance_threshold=self.distance_threshold,
                                 random_order=int(bool(random_order)), seed_base=int(seed), seed_stride=int(seed_stride),
-                                env_index_offset=int(env_index_offset))
+                                env_index_offset=int(env_index_offset), task_decomposition=int(self.task_decomposition),
+                                use_curriculum=int(self.curriculum), num_goals_to_generate=int(num_goals_to_generate))
         d = self.handle.dims
         self.dims = d
         self.action_space = spaces.Box(-np.ones([d.action_dim]), np.ones([d.action_dim]))
@@ -132,18 +147,65 @@ class KukaVecEnv:
 
     compute_reward = _compute_reward
 
-    # reference multi-step API (kuka_multi_step_base_env.py:147-181); the curriculum /
-    # task-decomposition bookkeeping is out of the hot path
+    # reference multi-step API (kuka_multi_step_base_env.py:142-177); one curriculum / sub-goal state PER ENV,
+    # as N separate reference envs would have
     def activate_curriculum_update(self):
-        warnings.warn('This method should not be called while not using curriculum.')
+        if not self.curriculum:
+            warnings.warn('This method should not be called while not using curriculum.')
+            return
+        self.curriculum_update = True
+        self.handle.curriculum_update(True)
 
     def deactivate_curriculum_update(self):
-        warnings.warn('This method should not be called while not using curriculum.')
+        if not self.curriculum:
+            warnings.warn('This method should not be called while not using curriculum.')
+            return
+        self.curriculum_update = False
+        self.handle.curriculum_update(False)
 
-    def set_sub_goal(self, sub_goal_ind):
-        warnings.warn('The set_sub_goal() method should only be called when using task decomposition,\n'
-                      'It does nothing and returns None when self.task_decomposition is False.')
-        return None
+    def set_sub_goal(self, sub_goal_ind, mask=None):
+        """kuka_multi_step_base_env.py:154-177: switch the desired goal to sub-goal ``sub_goal_ind`` (-1 = the
+        final goal) for all / the masked envs; returns the desired goals."""
+        if not self.task_decomposition:
+            warnings.warn('The set_sub_goal() method should only be called when using task decomposition,\n'
+                          'It does nothing and returns None when self.task_decomposition is False.')
+            return None
+        self.handle.set_sub_goal(sub_goal_ind, mask)
+        g = self.handle.read_outputs()[3]
+        g = g.astype(self.dtype) if self.dtype != np.float32 else g
+        return g if self.batched else g[0]
+
+    @property
+    def sub_goals(self):
+        """The reference's ``self.sub_goals`` list (kuka_multi_step_envs.py:89-122): entry k keeps the first k+1
+        blocks of the stacking order at their targets and every other block where it currently is."""
+        if not self.task_decomposition:
+            return None
+        st = self.handle.get_state()
+        nb = self.num_block
+        order = st[:, 40:40 + nb].astype(int)
+        targets = st[:, 48:48 + 3 * nb].reshape(-1, nb, 3)
+        blocks = np.stack([st[:, 64 + 13 * b:67 + 13 * b] for b in range(nb)], axis=1)
+        out = []
+        for k in range(nb):
+            g = blocks.copy()
+            for i in range(k + 1):
+                rows = np.arange(len(st))
+                g[rows, order[:, i]] = targets[rows, order[:, i]]
+            g = g.reshape(len(st), 3 * nb).astype(self.dtype)
+            out.append(g if self.batched else g[0])
+        return out
+
+    def _curriculum(self, idx):
+        if not self.curriculum:
+            return None
+        v = self.handle.curriculum_read()[idx]
+        return v if self.batched else v[0]
+
+    last_curriculum_level = property(lambda self: self._curriculum(0))
+    curriculum_goal_step = property(lambda self: self._curriculum(1))
+    curriculum_prob = property(lambda self: self._curriculum(2))
+    num_generated_goals_per_curriculum = property(lambda self: self._curriculum(3))
 
     def render(self, mode='human', camera_id=0):
         raise NotImplementedError('rendering / image observations are outside the accelerated hot path (state obs only)')

@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, 'oracle')
 
-TASKS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4}
+TASKS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4, 'block_rearrange': 5}
 
 
 class PmgConfig(C.Structure):
@@ -20,7 +20,8 @@ class PmgConfig(C.Structure):
                 ('binary_reward', C.c_int32), ('joint_control', C.c_int32), ('max_episode_steps', C.c_int32),
                 ('device', C.c_int32), ('distance_threshold', C.c_float), ('random_order', C.c_int32),
                 ('seed_base', C.c_uint64), ('seed_stride', C.c_uint64), ('env_index_offset', C.c_int32),
-                ('reserved', C.c_int32 * 7)]
+                ('task_decomposition', C.c_int32), ('use_curriculum', C.c_int32), ('num_goals_to_generate', C.c_int32),
+                ('reserved', C.c_int32 * 4)]
 
 
 class PmgDims(C.Structure):
@@ -30,7 +31,8 @@ class PmgDims(C.Structure):
 
 
 def make_config(task, num_envs, num_block=4, binary_reward=True, joint_control=False, max_episode_steps=50,
-                distance_threshold=0.05, seed_base=0, seed_stride=0, random_order=True, device=0, env_index_offset=0):
+                distance_threshold=0.05, seed_base=0, seed_stride=0, random_order=True, device=0, env_index_offset=0,
+                task_decomposition=False, use_curriculum=False, num_goals_to_generate=0):
     c = PmgConfig()
     c.struct_size = C.sizeof(PmgConfig)
     c.task = TASKS[task]
@@ -45,6 +47,9 @@ def make_config(task, num_envs, num_block=4, binary_reward=True, joint_control=F
     c.seed_base = seed_base
     c.seed_stride = seed_stride
     c.env_index_offset = env_index_offset
+    c.task_decomposition = int(task_decomposition)
+    c.use_curriculum = int(use_curriculum)
+    c.num_goals_to_generate = int(num_goals_to_generate)
     return c
 
 
@@ -128,6 +133,26 @@ class OracleEnv:
         ok = np.zeros(B, np.uint8)
         self.lib.pmgo_compute_reward(self.h, _fp(ag), _fp(dg), C.c_int64(B), _fp(r), _fp(ok))
         return r, ok.astype(bool)
+
+    def set_sub_goal(self, ind, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        rc = self.lib.pmgo_set_sub_goal(self.h, _fp(m), C.c_int32(ind))
+        if rc != 0:
+            raise RuntimeError(self.lib.pmgo_last_error(self.h).decode())
+
+    def curriculum_update(self, enabled):
+        rc = self.lib.pmgo_curriculum_update(self.h, C.c_int32(int(enabled)))
+        if rc != 0:
+            raise RuntimeError(self.lib.pmgo_last_error(self.h).decode())
+
+    def curriculum(self):
+        nb = self.cfg.num_block
+        lv, gs = np.zeros(self.N, np.int32), np.zeros(self.N, np.int32)
+        pr, gen = np.zeros((self.N, nb), np.float32), np.zeros((self.N, nb), np.float32)
+        rc = self.lib.pmgo_curriculum_read(self.h, _fp(lv), _fp(gs), _fp(pr), _fp(gen))
+        if rc != 0:
+            raise RuntimeError(self.lib.pmgo_last_error(self.h).decode())
+        return dict(level=lv, goal_step=gs, prob=pr, generated=gen)
 
     def get_state(self):
         s = np.zeros((self.N, self.dims.state_dim), np.float32)

@@ -111,3 +111,103 @@ def test_emulated_gripper_base_contact_matches_oracle(emu_library):
     so = _drive(env, ora, [[0, 0, 0, 1], [0, 0, -1, 1]])
     assert so[66] > 0.25                                         # held up by the contacts, not in free fall
     env.close()
+
+
+def _golden(name):
+    import json
+    return json.load(open(os.path.join(ROOT, 'tests', 'golden', name)))
+
+
+@pytest.mark.parametrize('key,task,kw', [
+    ('rearrange3/0', 'block_rearrange', {}),
+    ('rearrange5_curriculum/3', 'block_rearrange', {'use_curriculum': True}),
+    ('block_stack3_curriculum/3', 'block_stack', {'use_curriculum': True}),
+])
+def test_emulated_multistep_reset_matches_numpy_golden(emu_library, key, task, kw):
+    """The device reset kernel (MT19937, numpy choice(p=) / choice(replace=False), curriculum schedule) against the
+    vectors tools/gen_golden.py produced with the real numpy RandomState -- no oracle in between."""
+    g = _golden('multistep.json')
+    eps = g['episodes'][key]
+    nb = int(''.join(c for c in key.split('/')[0] if c.isdigit()))
+    seed = int(key.split('/')[1])
+    env = _make_quiet(task, emu_library, num_block=nb, seed=seed,
+                          num_goals_to_generate=g['num_goals_to_generate_per_block'] * nb, **kw)
+    # the constructor's reset consumed episode 0 with the update still off (as the reference's constructor does):
+    # the golden sequence counts from the first reset, so start the comparison from a fresh seed
+    if kw.get('use_curriculum'):
+        env.activate_curriculum_update()
+    env.seed(seed)
+    for ep in eps[:12]:
+        o = env.reset()
+        st = env.get_state()[0]
+        for b in range(nb):
+            assert np.array_equal(st[64 + 13 * b:67 + 13 * b], np.float32(ep['blocks'][b]))
+        assert np.array_equal(o['desired_goal'][0], np.float32(ep['desired_goal']))
+        if 'level' in ep:
+            assert env.last_curriculum_level[0] == ep['level'] and env.curriculum_goal_step[0] == ep['goal_step']
+            assert np.array_equal(env.curriculum_prob[0], np.float32(ep['prob']))
+            assert np.array_equal(env.num_generated_goals_per_curriculum[0], np.float32(ep['generated']))
+    env.close()
+
+
+def _make_quiet(task, lib, **kw):
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        return pmg.make_env(task=task, num_envs=1, seed_stride=1, _library=lib, **kw)
+
+
+def test_emulated_sub_goals_and_dynamic_goal_match_oracle(emu_library):
+    """task_decomposition: set_sub_goal(k) keeps the first k+1 blocks of the order at their targets and every other
+    block 'at its goal' wherever it currently is (kuka_multi_step_base_env.py:154-177,309-312), re-derived after
+    every step; reward follows the active sub-goal."""
+    nb = 3
+    env = _make_quiet('block_stack', emu_library, num_block=nb, seed=3, task_decomposition=True)
+    ora = O.OracleEnv('block_stack', 1, num_block=nb, seed_base=3, seed_stride=1, task_decomposition=True)
+    ora.reset()
+    o, oo = env.reset(), ora.reset()
+    assert np.array_equal(o['desired_goal'], oo['desired_goal'])          # sub_goal_ind = -1: the full stack
+    st = ora.get_state()[0]
+    order = st[40:40 + nb].astype(int)
+    for k in range(nb):
+        g = env.set_sub_goal(k)
+        ora.set_sub_goal(k)
+        ref = ora.reset(mask=np.zeros(1, bool))['desired_goal']          # re-observe without resetting
+        assert np.array_equal(g, ref)
+        assert np.array_equal(env.sub_goals[k], ref)
+        for i in range(nb):
+            b = order[i]
+            want = st[48 + 3 * b:51 + 3 * b] if i <= k else st[64 + 13 * b:67 + 13 * b]
+            assert np.array_equal(g[0, 3 * b:3 * b + 3], want)
+    # with sub-goal 0 active and block order[0] teleported onto its target, the step reports success
+    env.set_sub_goal(0), ora.set_sub_goal(0)
+    b0 = order[0]
+    st2 = ora.get_state().copy()
+    st2[0, 64 + 13 * b0:67 + 13 * b0] = st2[0, 48 + 3 * b0:51 + 3 * b0]
+    env.set_state(st2), ora.set_state(st2)
+    a = np.zeros((1, 4), np.float32)
+    o, r, d, info = env.step(a)
+    oo, ro, do, oko = ora.step(a)
+    assert np.abs(o['desired_goal'] - oo['desired_goal']).max() < 1e-5     # the other blocks' goals track their poses
+    assert info['goal_achieved'][0] and oko[0] and r[0] == 0.0 and ro[0] == 0.0
+    assert env.set_sub_goal(-1) is not None and not np.array_equal(env.set_sub_goal(-1), o['desired_goal'])
+    with pytest.raises(Exception):
+        env.set_sub_goal(nb)
+    env.close()
+
+
+def test_emulated_rearrange_step_matches_oracle(emu_library):
+    env = _make_quiet('block_rearrange', emu_library, num_block=2, seed=3)
+    ora = O.OracleEnv('block_rearrange', 1, num_block=2, seed_base=3, seed_stride=1)
+    ora.reset()
+    o, oo = env.reset(), ora.reset()
+    assert np.array_equal(o['desired_goal'], oo['desired_goal'])
+    assert np.abs(env.get_state() - ora.get_state()).max() < 1e-6
+    a = np.float32([[0.5, -1.0, 0.3]])
+    o, r, d, _ = env.step(a)
+    oo, ro, do, _ = ora.step(a)
+    assert o['observation'].shape == (1, 8 + 16 * 2) and env.dims.action_dim == 3
+    assert np.abs(o['observation'] - oo['observation']).max() < 2e-3
+    assert np.abs(o['observation'][0, 3]) == 0 and np.abs(o['observation'][0, 7]) == 0     # no gripper terms (kuka.py:245-246)
+    assert np.array_equal(r, ro) and np.array_equal(d, do)
+    env.close()

@@ -90,7 +90,7 @@ def test_compute_reward_batch(built):
 
 
 @pytest.mark.parametrize('task,kw', [('push', {}), ('pick_and_place', {}), ('pick_and_place', {'binary_reward': False}),
-                                     ('slide', {}), ('block_stack', {'num_block': 4})])
+                                     ('slide', {}), ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 3})])
 def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task, kw):
     """Contact-rich rollouts are chaotic and the PGS early exit makes velocities only ~3e-4 exact, so
     the HIP path is held to the float64 oracle within a small multiple of the oracle's OWN
@@ -159,6 +159,50 @@ def test_constructed_cylinder_contacts_match_oracle(built, scenario):
         assert (so[:, 65] > 0.055).all() and np.abs(so[:, 66] - 0.170).max() < 1e-3   # pushed along +y, still on the table
     else:
         assert (so[:, 66] > 0.25).mean() > 0.9                                          # held by the contacts
+    env.close()
+
+
+def test_multistep_bookkeeping_on_device(built):
+    """Curriculum draws / schedule against the numpy-generated golden vectors, and sub-goal switching against the
+    oracle, through the HIP library (8 envs, seed_stride 0: every env replays the golden sequence)."""
+    import json, os, warnings
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = json.load(open(os.path.join(root, 'tests', 'golden', 'multistep.json')))
+    N = 8
+    for key, task in [('rearrange3_curriculum/0', 'block_rearrange'), ('block_stack5_curriculum/3', 'block_stack')]:
+        nb = int(''.join(c for c in key.split('/')[0] if c.isdigit()))
+        seed = int(key.split('/')[1])
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            env = pmg.make_env(task=task, num_envs=N, num_block=nb, seed=seed, seed_stride=0, use_curriculum=True,
+                               num_goals_to_generate=g['num_goals_to_generate_per_block'] * nb)
+        env.activate_curriculum_update()
+        env.seed(seed)
+        for ep in g['episodes'][key]:
+            o = env.reset()
+            assert (o['desired_goal'] == np.float32(ep['desired_goal'])).all()
+            assert (env.last_curriculum_level == ep['level']).all() and (env.curriculum_goal_step == ep['goal_step']).all()
+            assert (env.curriculum_prob == np.float32(ep['prob'])).all()
+            assert (env.num_generated_goals_per_curriculum == np.float32(ep['generated'])).all()
+        s = env.get_state()
+        env.set_state(s)                                   # curriculum tail round-trips through get/set_state
+        assert np.array_equal(env.get_state(), s) and s.shape[1] == 64 + 13 * nb + 16
+        env.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = pmg.make_env(task='block_stack', num_envs=N, num_block=3, seed=0, seed_stride=1, task_decomposition=True)
+    ora = oracle_lib.OracleEnv('block_stack', N, num_block=3, seed_base=0, seed_stride=1, task_decomposition=True)
+    ora.reset()
+    env.reset(), ora.reset()
+    mask = np.arange(N) % 2 == 0
+    g1 = env.set_sub_goal(1, mask=mask)
+    ora.set_sub_goal(1, mask=mask)
+    ref = ora.reset(mask=np.zeros(N, bool))['desired_goal']
+    assert np.array_equal(g1, ref) and np.array_equal(env.sub_goals[1][mask], ref[mask])
+    a = np.zeros((N, 4), np.float32)
+    o, r, d, info = env.step(a)
+    oo, ro, do, oko = ora.step(a)
+    assert np.abs(o['desired_goal'] - oo['desired_goal']).max() < 1e-4 and np.array_equal(r, ro)
     env.close()
 
 

@@ -96,6 +96,94 @@ def stack_reset(rs, nb):
     return poses, order.tolist(), b.tolist(), np.concatenate(goal)
 
 
+class Curriculum:
+    """kuka_multi_step_base_env.py:121-140 (state) and :350-379 (_update_curriculum_prob), restated."""
+
+    def __init__(self, n, num_goals_to_generate):
+        self.n = n
+        self.prob = np.concatenate([[1.0], np.zeros(n - 1)])
+        self.per = num_goals_to_generate // n
+        self.count = np.zeros(n)
+        self.update = True
+
+    def draw(self, rs):
+        level = rs.choice(self.n, p=self.prob)            # the REAL numpy choice: pins the oracle's restatement
+        return int(level)
+
+    def account(self, level):
+        if not self.update:
+            return
+        self.count[level] += 1
+        fin = self.count >= self.per
+        half = self.count >= (self.per / 2)
+        self.prob[fin] = 0.0
+        if half[0] and not fin[0]:
+            self.prob[0] = 0.5; self.prob[1] = 0.5
+        for i in range(1, self.n - 1):
+            if fin[i - 1] and not fin[i]:
+                if half[i]:
+                    self.prob[i] = 0.5; self.prob[i + 1] = 0.5
+                else:
+                    self.prob[i] = 1.0
+        if fin[-2]:
+            self.prob[-1] = 1.0
+
+
+def multi_blocks(rs, nb, tip, obj_lo, obj_hi):
+    poses = []
+    for _ in range(nb):
+        while True:
+            xy = rs.uniform(obj_lo[:-1], obj_hi[:-1])
+            if all(np.linalg.norm(xy - p[:-1]) > 0.06 for p in poses + [tip]):
+                poses.append(np.concatenate((xy, [0.175])))
+                break
+    return poses
+
+
+def stack_curriculum_reset(rs, nb, cur):
+    """kuka_multi_step_envs.py:34-87 + :124-148 with use_curriculum=True."""
+    poses, order, base, goal = stack_reset(rs, nb)
+    level = cur.draw(rs)
+    cur.account(level)
+    targets = [[base[0], base[1], 0.175 + 0.03 * k] for k in range(nb)]
+    dg = [None] * nb
+    for i in range(nb):
+        dg[order[i]] = targets[i] if i <= level else poses[order[i]].tolist()
+    return {'blocks': [p.tolist() for p in poses], 'order': order, 'base': base, 'level': level,
+            'goal_step': level * 25 + 50, 'desired_goal': np.concatenate(dg).tolist(),
+            'prob': cur.prob.tolist(), 'generated': cur.count.tolist()}
+
+
+def rearrange_reset(rs, nb, cur=None):
+    """kuka_multi_step_envs.py:174-227 (tip starts on the table: kuka_multi_step_envs.py:169)."""
+    tip, obj_lo, obj_hi, tgt_lo, tgt_hi = boxes('push')
+    poses = multi_blocks(rs, nb, tip, obj_lo, obj_hi)
+    targets = []
+    for _ in range(nb):
+        while True:
+            xy = rs.uniform(tgt_lo[:-1], tgt_hi[:-1])
+            if all(np.linalg.norm(xy - p[:-1]) > 0.06 for p in targets + poses):
+                targets.append(np.concatenate((xy, [0.175])))
+                break
+    out = {'blocks': [p.tolist() for p in poses], 'targets': [t.tolist() for t in targets]}
+    if cur is None:
+        out['desired_goal'] = np.concatenate(targets).tolist()
+        return out
+    level = cur.draw(rs)
+    moved = np.sort(rs.choice(np.arange(nb), size=level + 1, replace=False), kind='stable').tolist()
+    cur.account(level)
+    tq = [t.copy() for t in targets]
+    dg = []
+    for i in range(nb):
+        if i in moved:
+            dg.append(tq[0].copy()); del tq[0]
+        else:
+            dg.append(poses[i].copy())
+    out.update({'level': level, 'goal_step': level * 25 + 50, 'moved': [int(m) for m in moved],
+                'desired_goal': np.concatenate(dg).tolist(), 'prob': cur.prob.tolist(), 'generated': cur.count.tolist()})
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = {}
@@ -125,6 +213,32 @@ def main():
                 eps.append({'blocks': [p.tolist() for p in poses], 'order': order, 'base': base, 'goal': goal.tolist()})
             samp['block_stack%d/%d' % (nb, seed)] = eps
     json.dump(samp, open(os.path.join(OUT, 'sampling.json'), 'w'), indent=0)
+
+    # multi-step bookkeeping: block_rearrange sampling, and the curriculum draw / probability schedule with a
+    # small goal budget (num_goals_to_generate = 8*nb) so that every probability transition is walked through
+    def episodes(fn, count):
+        # the reference's schedule can leave prob summing to 0.5 when level i+1 uses up its budget before level i
+        # (numpy then raises "probabilities do not sum to 1" inside the reference): the sequence stops there
+        out = []
+        for _ in range(count):
+            try:
+                out.append(fn())
+            except ValueError:
+                break
+        return out
+
+    multi = {}
+    for nb in [2, 3, 5]:
+        for seed in [0, 3]:
+            rs, _ = gym_np_random(seed)
+            multi['rearrange%d/%d' % (nb, seed)] = [rearrange_reset(rs, nb) for _ in range(4)]
+            rs, _ = gym_np_random(seed)
+            cur = Curriculum(nb, 8 * nb)
+            multi['rearrange%d_curriculum/%d' % (nb, seed)] = episodes(lambda: rearrange_reset(rs, nb, cur), 10 * nb)
+            rs, _ = gym_np_random(seed)
+            cur = Curriculum(nb, 8 * nb)
+            multi['block_stack%d_curriculum/%d' % (nb, seed)] = episodes(lambda: stack_curriculum_reset(rs, nb, cur), 10 * nb)
+    json.dump({'num_goals_to_generate_per_block': 8, 'episodes': multi}, open(os.path.join(OUT, 'multistep.json'), 'w'), indent=0)
 
     fk = {'rest_pose': [0, -0.5592432, 0, 1.733180, 0, -0.8501557, 0, 0.035, 0.035],
           'tip_position': [-0.522923, 0.0, 0.250773], 'tip_position_tol': 1e-5,
