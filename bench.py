@@ -49,6 +49,17 @@ def committed_traffic(task, n_envs):
     return None if best is None else float(best['hbm_bytes_per_launch'])
 
 
+def committed_valu(task, n_envs):
+    """SQ_INSTS_VALU per pmg_k_step launch from the committed PMC pass (profiles/*_pmc_summary.json), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s%d_pmc_summary.json' % (task, n_envs))), reverse=True):
+        try:
+            return float(json.load(open(f))['SQ_INSTS_VALU']['mean_per_launch'])
+        except Exception:
+            continue
+    return None
+
+
 def usable_cores():
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -179,6 +190,13 @@ def main():
                          'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by '
                                  'construction (SURVEY.md 8d); the binding resource is VALU issue / dependency latency'},
         }
+        vi = committed_valu(args.task, N)
+        if vi is not None and kernel_ms > 0:
+            # the resource that actually binds this path: wave64 VALU issue, 1 instruction / 4 cycles / SIMD,
+            # 1024 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+            out['roofline']['valu'] = {'insts_per_launch': vi, 'peak_insts_per_s': 1024 * 2.4e9 / 4,
+                                       'util': vi / (kernel_ms * 1e-3) / (1024 * 2.4e9 / 4),
+                                       'source': 'SQ_INSTS_VALU of the committed rocprofv3 --pmc pass over the live kernel time'}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.task)
         print(json.dumps(out), flush=True)

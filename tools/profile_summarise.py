@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of tools/profile.sh into the small summaries committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+
+task, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'r01')
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, 'gpurun_out', 'prof_' + task)
+dst = os.path.join(root, 'gpurun_out', 'profiles')
+os.makedirs(dst, exist_ok=True)
+ALGO = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242}
+
+stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
+if stats:
+    rows = list(csv.reader(open(stats[0])))
+    with open(os.path.join(dst, '%s_%s4096_kernel_stats.csv' % (tag, task)), 'w') as f:
+        csv.writer(f).writerows(rows)
+    print('kernel stats:', rows[1][:4] if len(rows) > 1 else rows)
+
+summary = {}
+for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
+    if not os.path.isdir(d):
+        continue
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(f)):
+            if not r.get('Kernel_Name', '').startswith('void pmg_k_step'):
+                continue
+            acc.setdefault(r['Counter_Name'], {}).setdefault(r['Dispatch_Id'], 0.0)
+            acc[r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
+        for name, per in acc.items():
+            summary[name] = {'launches': len(per), 'mean_per_launch': sum(per.values()) / len(per), 'pass': os.path.basename(d)}
+json.dump(summary, open(os.path.join(dst, '%s_%s4096_pmc_summary.json' % (tag, task)), 'w'), indent=1, sort_keys=True)
+if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
+    fk, wk = summary['FETCH_SIZE']['mean_per_launch'], summary['WRITE_SIZE']['mean_per_launch']
+    json.dump({'task': task, 'envs_per_gpu': 4096,
+               'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --task %s --steps 50 --warmup 5 --no-cpu-baseline' % task,
+               'kernel': 'pmg_k_step', 'FETCH_SIZE_KiB': fk, 'WRITE_SIZE_KiB': wk, 'hbm_bytes_per_launch': (fk + wk) * 1024.0,
+               'algorithmic_bytes_per_launch': ALGO[task] * 4096,
+               'note': 'counters are KiB; dword accesses, so the guide\'s x2 FETCH correction for 16 B/lane streams is NOT applied'},
+              open(os.path.join(dst, '%s_%s4096_pmc_traffic.json' % (tag, task)), 'w'), indent=1)
+print(json.dumps({k: round(v['mean_per_launch']) for k, v in summary.items()}))
