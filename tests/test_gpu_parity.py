@@ -257,3 +257,41 @@ def test_rccl_single_rank_allgather_and_kernel_timer(built):
     h.device_free(a)
     h.device_free(out)
     env.close()
+
+
+@pytest.mark.parametrize('task,N,kw', [('pick_and_place', 8192, {'binary_reward': False}),      # BASELINE.json configs[3]
+                                       ('block_stack', 4096, {'num_block': 4}),                  # configs[4]
+                                       ('push', 4096, {})])                                      # configs[2]
+def test_full_size_contact_configs_properties(built, task, N, kw):
+    """The BASELINE.json contact configurations at their full batch sizes, through size-independent properties:
+    bit-identical replay from a restored state, batch-permutation equivariance, physical invariants (nothing falls
+    through the table, objects stay finite and on / above it), reward consistent with the returned goals."""
+    env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, **kw)
+    A = env.dims.action_dim
+    rs = np.random.RandomState(7)
+    env.reset()
+    for _ in range(2):
+        env.step(rs.uniform(-1, 1, (N, A)).astype(np.float32))
+    s0 = env.get_state()
+    a = rs.uniform(-1, 1, (N, A)).astype(np.float32)
+    o1, r1, d1, i1 = env.step(a)
+    s1 = env.get_state()
+    env.set_state(s0)
+    o2, r2, d2, i2 = env.step(a)
+    assert np.array_equal(o1['observation'], o2['observation']) and np.array_equal(r1, r2) and np.array_equal(s1, env.get_state())
+    perm = np.random.RandomState(8).permutation(N)
+    env.set_state(s0[perm])
+    o3, r3, _, _ = env.step(a[perm])
+    assert np.array_equal(o3['observation'], o1['observation'][perm]) and np.array_equal(r3, r1[perm])
+    assert np.isfinite(o1['observation']).all()
+    ag = o1['achieved_goal'].reshape(N, -1, 3)
+    assert (ag[..., 2] > 0.17).all() and (ag[..., 2] < 0.6).all()           # on the table (top 0.16 + half 0.015) or lifted
+    assert (np.abs(ag[..., 0] + 0.52) < 0.35).all() and (np.abs(ag[..., 1]) < 0.4).all()
+    d = np.linalg.norm(o1['achieved_goal'].astype(np.float64) - o1['desired_goal'], axis=-1)
+    if kw.get('binary_reward', True):
+        clear = np.abs(d - 0.05) > 1e-4
+        assert np.array_equal(r1[clear], -(d > 0.05).astype(np.float32)[clear])
+    else:
+        assert np.abs(r1 + d).max() < 1e-5
+    assert np.array_equal(i1['goal_achieved'][np.abs(d - 0.05) > 1e-4], (d <= 0.05)[np.abs(d - 0.05) > 1e-4])
+    env.close()
