@@ -15,6 +15,14 @@
 #include "pmg_device.h"
 
 namespace pmg {
+#ifdef PMG_PROFILE
+__device__ long long g_phase[16];
+#define PMG_PH0() long long ph_t_ = wall_clock64()
+#define PMG_PH(i) do { long long n_ = wall_clock64(); if (wv::lane() == 0 && blockIdx.x == 0) g_phase[i] += n_ - ph_t_; ph_t_ = wall_clock64(); } while (0)
+#else
+#define PMG_PH0() do { } while (0)
+#define PMG_PH(i) do { } while (0)
+#endif
 
 constexpr float CONTACT_MARGIN = 0.002f;
 constexpr float EDGE_FUDGE = 1.05f;
@@ -721,6 +729,7 @@ template <int NB, int MAXC, bool CYL>
 __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const float* table_c, const float* table_h, float table_mu)
 {
     using OB = ObjT<CYL>;
+    PMG_PH0();
     int l = wv::lane();
     int npair = nb + nb * (nb - 1) / 2 + 2 * (nb + 1) + (OB::cyl ? 0 : nb);
     const float I3[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
@@ -794,6 +803,7 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
         L.pair_count[i] = n;
     }
     wv::lds_sync();
+    PMG_PH(0);
     int total = 0;
     for (int i = l; i < npair; i += 64) {
         int off = 0;
@@ -814,6 +824,7 @@ __device__ __forceinline__ int collide(ContactLds<NB, MAXC>& L, int nb, const fl
     for (int j = 0; j < npair; j++) total += L.pair_count[j];
     if (total > MAXC) total = MAXC;
     wv::lds_sync();
+    PMG_PH(1);
     return total;
 }
 
@@ -835,6 +846,7 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
 {
     using OB = ObjT<CYL>;
     using LY = RowLayout<NB>;
+    PMG_PH0();
     int l = wv::lane();
     /* R1 */
     for (int c = l; c < nc; c += 64) {
@@ -883,6 +895,7 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
         }
     }
     wv::lds_sync();
+    PMG_PH(2);
     /* R2 */
     for (int item = l; item < 27 * nc; item += 64) {
         int c = item / 27, t = (item / 9) % 3, d = item % 9;
@@ -904,6 +917,7 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
         row[d] = acc;
     }
     wv::lds_sync();
+    PMG_PH(3);
     /* R3 */
     for (int item = l; item < 27 * nc; item += 64) {
         int c = item / 27, t = (item / 9) % 3, i = item % 9;
@@ -916,6 +930,7 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
         }
     }
     wv::lds_sync();
+    PMG_PH(4);
     /* R4 */
     for (int c = l; c < nc; c += 64) {
         float dist = L.con[c][11] + LINEAR_SLOP;
@@ -942,6 +957,7 @@ __device__ __forceinline__ void build_contact_rows(ContactLds<NB, MAXC>& L, int 
         }
     }
     wv::lds_sync();
+    PMG_PH(5);
 }
 
 /* ---------------------------------------------------------------- */

@@ -37,6 +37,7 @@ int main(int argc, char** argv)
         long long pr[16]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
         printf("task %d rep %d kernel %.3f ms | ticks/substep (100MHz): fk %.0f detect %.0f dyn %.0f rows %.0f pgs %.0f | whole-step ticks: ik %lld loop %lld out %lld | nc %.0f con %.0f\n", task, rep, ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5], pr[6], pr[7], pr[8]/100., pr[9]/100.);
     }
+    { long long ph[16]; hipMemcpyFromSymbol(ph, HIP_SYMBOL(pmg::g_phase), sizeof(ph)); printf("phase ticks/substep (3 reps): collide-narrow %.0f compact %.0f | R1 %.0f R2 %.0f R3 %.0f R4 %.0f\n", ph[0]/300., ph[1]/300., ph[2]/300., ph[3]/300., ph[4]/300., ph[5]/300.); }
     std::vector<float> h2(N*32); hipMemcpy(h2.data(), P.hot, h2.size()*4, hipMemcpyDeviceToHost); printf("q0 after: %f %f %f ee z %f\n", h2[1], h2[3], h2[5], h2[20]);
     return 0;
 }
