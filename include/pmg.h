@@ -76,7 +76,9 @@ typedef struct pmg_config {
     int32_t task_decomposition; /* block_stack: sub-goals, kuka_multi_step_envs.py:89-122 (excludes use_curriculum) */
     int32_t use_curriculum;     /* block_stack / block_rearrange: kuka_multi_step_base_env.py:121-140 (num_block >= 2) */
     int32_t num_goals_to_generate; /* curriculum budget, P/__init__.py:11 (default 1e6); 0 = 1e6 */
-    int32_t reserved[4];
+    int32_t grip_informed_goal; /* block_stack: goals carry the gripper tip target + finger width (kuka_multi_step_envs.py:75-77);
+                                   goal_dim = 3*num_block + 4, sub-goals double (pick / place) */
+    int32_t reserved[3];
 } pmg_config;
 
 typedef struct pmg_dims {
@@ -153,7 +155,7 @@ int pmg_set_goal(pmg_env* env, const uint8_t* mask, const float* goals);
  *
  * Replaces: KukaBulletMultiBlockEnv.set_sub_goal (kuka_multi_step_base_env.py:154-177): sub-goal index for
  * the masked envs (mask NULL = all), -1 = the final goal, as after reset; refreshes desired_goal in the output
- * buffers.  PMG_E_STATE unless the handle was created with task_decomposition. */
+ * buffers.  Valid indices: [-1, num_block), or [-1, 2*num_block) with grip_informed_goal (pick, place, pick, ...).  PMG_E_STATE unless the handle was created with task_decomposition. */
 int pmg_set_sub_goal(pmg_env* env, const uint8_t* mask, int32_t sub_goal_ind);
 /* Replaces: activate_curriculum_update / deactivate_curriculum_update (kuka_multi_step_base_env.py:142-152). */
 int pmg_curriculum_update(pmg_env* env, int32_t enabled);

@@ -1783,7 +1783,8 @@ static void task_reset_multi(const pmgo_env* e, World* w)
     }
     for (int b = 0; b < e->nb; b++) set_block(&w->blk[b], (real)bp[b][0], (real)bp[b][1], (real)0.175);
     for (int b = 0; b < NBMAX; b++) w->order[b] = b;
-    w->level = e->nb - 1;
+    /* sub_goal_ind = -1 after reset (kuka_multi_step_base_env.py:248-249): the last sub-goal */
+    w->level = (e->cfg.grip_informed_goal && e->cfg.task_decomposition) ? 2 * e->nb - 1 : e->nb - 1;
     w->moved = (1 << e->nb) - 1;
     if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
         if (e->cfg.random_order)
@@ -1825,9 +1826,20 @@ static void effective_goal(const pmgo_env* e, const World* w, double* dg)
     int G = e->dims.goal_dim;
     if (!e->multi) { for (int g = 0; g < G; g++) dg[g] = w->goal[g]; return; }
     if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
+        /* plain / curriculum: the first level+1 blocks of the order sit at their targets.  grip-informed sub-goals
+         * come in (pick, place) pairs per block j (kuka_multi_step_envs.py:91-111): pick keeps blocks i < j, place
+         * blocks i <= j at their targets */
+        int pairs = e->cfg.grip_informed_goal && e->cfg.task_decomposition;
+        int j = pairs ? w->level / 2 : w->level, pick = pairs && (w->level % 2 == 0);
         for (int s_ = 0; s_ < e->nb; s_++) {
             int b = w->order[s_];
-            for (int a = 0; a < 3; a++) dg[3 * b + a] = s_ <= w->level ? w->goal[3 * b + a] : w->blk[b].pos[a];
+            int at_target = pick ? s_ < j : s_ <= j;
+            for (int a = 0; a < 3; a++) dg[3 * b + a] = at_target ? w->goal[3 * b + a] : w->blk[b].pos[a];
+        }
+        if (e->cfg.grip_informed_goal) { /* gripper tip target + finger width 0.03 (:75-77, :98-99, :108-109, :143-145) */
+            int bj = w->order[j];
+            for (int a = 0; a < 3; a++) dg[3 * e->nb + a] = pick ? w->blk[bj].pos[a] : w->goal[3 * bj + a];
+            dg[3 * e->nb + 3] = 0.03;
         }
     } else {
         int k = 0;
@@ -1885,6 +1897,10 @@ static void env_obs(const pmgo_env* e, const World* w, float* obs, float* pol, f
             for (int a = 0; a < 3; a++) o[no++] = tw[a] - bl->omg[a];
             if (ag) for (int a = 0; a < 3; a++) ag[3 * b + a] = (float)bl->pos[a];
         }
+        if (ag && e->cfg.grip_informed_goal) { /* :300-304 */
+            for (int a = 0; a < 3; a++) ag[3 * e->nb + a] = (float)tip[a];
+            ag[3 * e->nb + 3] = (float)closeness;
+        }
         for (int i = 0; i < no; i++) o[i] = o[i] < -5 ? -5 : (o[i] > 5 ? 5 : o[i]);  /* :306-307 */
         for (int i = 0; i < np; i++) p[i] = p[i] < -5 ? -5 : (p[i] > 5 ? 5 : p[i]);
     } else if (e->has_obj) {
@@ -1908,7 +1924,7 @@ static void env_obs(const pmgo_env* e, const World* w, float* obs, float* pol, f
     if (obs) for (int i = 0; i < no; i++) obs[i] = (float)o[i];
     if (pol) for (int i = 0; i < np; i++) pol[i] = (float)p[i];
     if (dg) {
-        double d64[16];
+        double d64[20];
         effective_goal(e, w, d64);
         for (int i = 0; i < G; i++) dg[i] = (float)d64[i];
     }
@@ -1974,11 +1990,16 @@ static int fill_dims(const pmg_config* c, pmg_dims* d)
         if (c->task_decomposition && c->task != PMG_TASK_BLOCK_STACK) return -1;          /* kuka_multi_step_envs.py:159 */
         int gr = c->task == PMG_TASK_BLOCK_STACK;
         d->action_dim = (jo ? 7 : 3) + gr; d->observation_dim = 8 + 16 * c->num_block + jo;
-        d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; break;
+        d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; 
+        if (c->grip_informed_goal) {
+            if (!gr) return -1;                       /* kuka_multi_step_envs.py:158: not for block_rearrange */
+            d->goal_dim += 4;                         /* tip xyz + finger width, kuka_multi_step_base_env.py:300-304 */
+        }
+        break;
     }
     default: return -1;
     }
-    if (c->task != PMG_TASK_BLOCK_STACK && c->task != PMG_TASK_BLOCK_REARRANGE && (c->use_curriculum || c->task_decomposition)) return -1;
+    if (c->task != PMG_TASK_BLOCK_STACK && c->task != PMG_TASK_BLOCK_REARRANGE && (c->use_curriculum || c->task_decomposition || c->grip_informed_goal)) return -1;
     int multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE;
     int nb = c->task == PMG_TASK_REACH ? 0 : (multi ? c->num_block : 1);
     d->state_dim = 64 + 13 * nb + (c->use_curriculum ? 16 : 0);
@@ -2066,10 +2087,10 @@ int pmgo_step(pmgo_env* e, const float* actions, float* obs, float* pol, float* 
     for (int i = 0; i < N; i++) {
         World* w = &e->w[i];
         env_step_one(e, w, actions + (size_t)i * dm->action_dim);
-        float agl[16], dgl[16];
+        float agl[20], dgl[20];
         env_obs(e, w, obs ? obs + (size_t)i * dm->observation_dim : NULL, pol ? pol + (size_t)i * dm->policy_state_dim : NULL, agl, dgl);
         /* reward from the double-precision goals (the reference's obs are float64) */
-        double a64[16], d64[16];
+        double a64[20], d64[20];
         effective_goal(e, w, d64);
         if (e->cfg.task == PMG_TASK_REACH) {
             Kin k; kinematics(w->q, &k);
@@ -2077,6 +2098,13 @@ int pmgo_step(pmgo_env* e, const float* actions, float* obs, float* pol, float* 
         } else {
             for (int b = 0; b < e->nb; b++)
                 for (int g = 0; g < 3; g++) a64[3 * b + g] = w->blk[b].pos[g];
+            if (e->cfg.grip_informed_goal) {
+                Kin k; kinematics(w->q, &k);
+                real dd[3];
+                v3sub(dd, k.p[PMG_BL_TAB1], k.p[PMG_BL_TAB2]);
+                for (int g = 0; g < 3; g++) a64[3 * e->nb + g] = k.p[PMG_BL_TIP][g];
+                a64[3 * e->nb + 3] = v3norm(dd);
+            }
         }
         float r; uint8_t ok;
         reward_f64(e, a64, d64, dm->goal_dim, &r, &ok);
@@ -2093,7 +2121,7 @@ int pmgo_compute_reward(pmgo_env* e, const float* ag, const float* dg, int64_t b
 {
     int G = e->dims.goal_dim;
     for (int64_t i = 0; i < batch; i++) {
-        double a[16], d[16];
+        double a[20], d[20];
         for (int g = 0; g < G; g++) { a[g] = ag[i * G + g]; d[g] = dg[i * G + g]; }
         float r; uint8_t o;
         reward_f64(e, a, d, G, &r, &o);
@@ -2170,7 +2198,7 @@ int pmgo_set_goal(pmgo_env* e, const uint8_t* mask, const float* goals)
     int G = e->dims.goal_dim;
     for (int i = 0; i < e->cfg.num_envs; i++)
         if (!mask || mask[i])
-            for (int g = 0; g < G; g++) e->w[i].goal[g] = goals[(size_t)i * G + g];
+            for (int g = 0; g < G && g < 15; g++) e->w[i].goal[g] = goals[(size_t)i * G + g]; /* static targets only */
     return PMG_OK;
 }
 
@@ -2178,9 +2206,10 @@ int pmgo_set_goal(pmgo_env* e, const uint8_t* mask, const float* goals)
 int pmgo_set_sub_goal(pmgo_env* e, const uint8_t* mask, int32_t ind)
 {
     if (!e->cfg.task_decomposition) { snprintf(e->err, sizeof(e->err), "pmgo_set_sub_goal: task_decomposition is off"); return PMG_E_STATE; }
-    if (ind < -1 || ind >= e->nb) { snprintf(e->err, sizeof(e->err), "pmgo_set_sub_goal: index %d out of range", ind); return PMG_E_INVALID; }
+    int steps = e->cfg.grip_informed_goal ? 2 * e->nb : e->nb; /* kuka_multi_step_envs.py:13-17 */
+    if (ind < -1 || ind >= steps) { snprintf(e->err, sizeof(e->err), "pmgo_set_sub_goal: index %d out of range", ind); return PMG_E_INVALID; }
     for (int i = 0; i < e->cfg.num_envs; i++)
-        if (!mask || mask[i]) e->w[i].level = ind < 0 ? e->nb - 1 : ind;
+        if (!mask || mask[i]) e->w[i].level = ind < 0 ? steps - 1 : ind;
     return PMG_OK;
 }
 int pmgo_curriculum_update(pmgo_env* e, int32_t enabled)

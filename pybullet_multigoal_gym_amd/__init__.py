@@ -46,16 +46,16 @@ def make_env(task='reach', gripper='parallel_jaw', num_block=5, render=False, bi
         unsupported('push primitives')
     if state_noise:
         unsupported('state_noise')
-    if grip_informed_goal:
-        unsupported('grip_informed_goal')
     if task in ('block_stack', 'block_rearrange'):
         assert num_block <= 5, "only support up to 5 blocks"
         if task == 'block_rearrange':   # kuka_multi_step_envs.py:158-159
             assert not task_decomposition, 'Block rearranging task does not support task decomposition.'
-    elif task_decomposition or use_curriculum:
-        unsupported('task_decomposition / use_curriculum outside block_stack and block_rearrange')
+            assert not grip_informed_goal, 'Block rearranging task does not support gripper informed goal representation.'
+    elif task_decomposition or use_curriculum or grip_informed_goal:
+        unsupported('task_decomposition / use_curriculum / grip_informed_goal outside block_stack and block_rearrange')
     return KukaVecEnv(task=task, num_envs=num_envs, binary_reward=binary_reward, joint_control=joint_control,
                       max_episode_steps=max_episode_steps, distance_threshold=distance_threshold, num_block=num_block,
                       seed=seed, seed_stride=seed_stride, device=device, env_index_offset=env_index_offset,
                       dtype=dtype, task_decomposition=task_decomposition, use_curriculum=use_curriculum,
-                      num_goals_to_generate=num_goals_to_generate, _library=_library)
+                      num_goals_to_generate=num_goals_to_generate, grip_informed_goal=grip_informed_goal,
+                      _library=_library)

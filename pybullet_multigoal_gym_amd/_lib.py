@@ -22,7 +22,7 @@ class PmgConfig(C.Structure):
                 ('device', C.c_int32), ('distance_threshold', C.c_float), ('random_order', C.c_int32),
                 ('seed_base', C.c_uint64), ('seed_stride', C.c_uint64), ('env_index_offset', C.c_int32),
                 ('task_decomposition', C.c_int32), ('use_curriculum', C.c_int32), ('num_goals_to_generate', C.c_int32),
-                ('reserved', C.c_int32 * 4)]
+                ('grip_informed_goal', C.c_int32), ('reserved', C.c_int32 * 3)]
 
 
 class PmgDims(C.Structure):

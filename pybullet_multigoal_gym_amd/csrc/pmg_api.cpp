@@ -147,11 +147,16 @@ int fill_dims(const pmg_config* c, pmg_dims* d, int* nb_out)
         if (c->use_curriculum && (c->num_block < 2 || c->task_decomposition)) return -1; /* kuka_multi_step_base_env.py:123,131 */
         if (c->task_decomposition && c->task != PMG_TASK_BLOCK_STACK) return -1;          /* kuka_multi_step_envs.py:159 */
         d->action_dim = (jo ? 7 : 3) + (c->task == PMG_TASK_BLOCK_STACK ? 1 : 0); d->observation_dim = 8 + 16 * c->num_block + jo;
-        d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block; break;
+        d->policy_state_dim = 4 + 3 * c->num_block + jo; d->goal_dim = 3 * c->num_block;
+        if (c->grip_informed_goal) {
+            if (c->task != PMG_TASK_BLOCK_STACK) return -1; /* kuka_multi_step_envs.py:158 */
+            d->goal_dim += 4;                               /* tip xyz + finger width, kuka_multi_step_base_env.py:300-304 */
+        }
+        break;
     default: return -1;
     }
     bool multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE;
-    if (!multi && (c->use_curriculum || c->task_decomposition)) return -1;
+    if (!multi && (c->use_curriculum || c->task_decomposition || c->grip_informed_goal)) return -1;
     int nb = c->task == PMG_TASK_REACH ? 0 : (multi ? c->num_block : 1);
     *nb_out = nb;
     d->state_dim = 64 + 13 * nb + (c->use_curriculum ? pmg::CURR_DIM : 0);
@@ -173,6 +178,7 @@ void fill_params(pmg_env* e)
     P.random_order = c.random_order;
     P.multi = (t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_BLOCK_REARRANGE);
     P.curriculum = c.use_curriculum; P.curriculum_update = 0;
+    P.decomposition = c.task_decomposition; P.grip_goal = c.grip_informed_goal;
     {
         double total = c.num_goals_to_generate > 0 ? (double)c.num_goals_to_generate : 1e6;
         P.goals_per_curriculum = e->nb > 0 ? floor(total / e->nb) : total; /* kuka_multi_step_base_env.py:139 */
@@ -551,7 +557,7 @@ int pmg_set_goal(pmg_env* e, const uint8_t* mask, const float* goals)
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     HIP_TRY(e, hipMemcpy(goal.data(), e->P.goal, goal.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < N; i++)
-        if (!mask || mask[i]) memcpy(&goal[i * pmg::GOAL_DIM], goals + i * G, sizeof(float) * G);
+        if (!mask || mask[i]) memcpy(&goal[i * pmg::GOAL_DIM], goals + i * G, sizeof(float) * (G < 15 ? G : 15)); /* static targets only */
     HIP_TRY(e, hipMemcpy(e->P.goal, goal.data(), goal.size() * sizeof(float), hipMemcpyHostToDevice));
     return PMG_OK;
 }
@@ -560,7 +566,8 @@ int pmg_set_sub_goal(pmg_env* e, const uint8_t* mask, int32_t sub_goal_ind)
 {
     if (!e) return PMG_E_INVALID;
     if (!e->cfg.task_decomposition) return fail(e, PMG_E_STATE, "pmg_set_sub_goal: the handle was created without task_decomposition");
-    if (sub_goal_ind < -1 || sub_goal_ind >= e->nb) return fail(e, PMG_E_INVALID, "pmg_set_sub_goal: index %d out of range [-1, %d)", sub_goal_ind, e->nb);
+    const int steps = e->cfg.grip_informed_goal ? 2 * e->nb : e->nb; /* kuka_multi_step_envs.py:13-17 */
+    if (sub_goal_ind < -1 || sub_goal_ind >= steps) return fail(e, PMG_E_INVALID, "pmg_set_sub_goal: index %d out of range [-1, %d)", sub_goal_ind, steps);
     if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_set_sub_goal: reset first");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const unsigned char* dm = nullptr;
@@ -568,7 +575,7 @@ int pmg_set_sub_goal(pmg_env* e, const uint8_t* mask, int32_t sub_goal_ind)
         HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, (size_t)e->dims.num_envs, hipMemcpyHostToDevice, e->stream));
         dm = e->d_mask;
     }
-    HIP_TRY(e, pmg_launch_sub_goal(e->P, dm, sub_goal_ind < 0 ? e->nb - 1 : sub_goal_ind, e->stream));
+    HIP_TRY(e, pmg_launch_sub_goal(e->P, dm, sub_goal_ind < 0 ? steps - 1 : sub_goal_ind, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return PMG_OK;
 }

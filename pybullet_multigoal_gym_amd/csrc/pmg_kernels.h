@@ -24,6 +24,7 @@ struct EnvParams {
     int n_envs, task, nb, grasping, has_obj, joint_control, binary_reward, max_steps, in_air, random_order;
     int multi;              /* multi-block observation layout: block_stack / block_rearrange */
     int curriculum, curriculum_update; /* kuka_multi_step_base_env.py:121-152 */
+    int decomposition, grip_goal;      /* task_decomposition, grip_informed_goal (goal = blocks | tip target | finger width) */
     double goals_per_curriculum;
     int adim, odim, pdim, gdim, packed;
     float thr;
@@ -58,9 +59,20 @@ __device__ __forceinline__ float effective_goal_at_level(const EnvParams& P, int
     const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
     int b = i / 3, a = i - 3 * b;
     if (P.task == PMG_TASK_BLOCK_STACK) {
+        /* plain / curriculum: the first level+1 blocks of the order sit at their targets.  grip-informed sub-goals
+         * come in (pick, place) pairs per block j (kuka_multi_step_envs.py:91-111): pick keeps blocks i < j, place
+         * blocks i <= j at their targets; the tail is the gripper tip target and the finger width 0.03 */
+        const bool pairs = P.grip_goal && P.decomposition;
+        const int j = pairs ? level / 2 : level;
+        const bool pick = pairs && (level % 2 == 0);
+        if (i >= 3 * P.nb) {
+            if (i == 3 * P.nb + 3) return 0.03f;
+            int bj = (int)cold[8 + j];
+            return pick ? bb[BLOCK_DIM * bj + a] : g[3 * bj + a];
+        }
         int pos = 0;
         for (int s = 0; s < P.nb; s++) pos = ((int)cold[8 + s] == b) ? s : pos;   /* place of block b in the stack order */
-        return pos <= level ? g[i] : bb[BLOCK_DIM * b + a];
+        return (pick ? pos < j : pos <= j) ? g[i] : bb[BLOCK_DIM * b + a];
     }
     int moved = (int)g[15];
     if (!((moved >> b) & 1)) return bb[BLOCK_DIM * b + a];
@@ -169,6 +181,10 @@ __device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const
 #pragma unroll
             for (int a = 0; a < 4; a++) s[6 + a] = b[3 + a];
         }
+        if (P.grip_goal && l == 0) { /* kuka_multi_step_base_env.py:300-304 */
+            float* t = ag + 3 * P.nb;
+            t[0] = tip[0]; t[1] = tip[1]; t[2] = tip[2]; t[3] = closeness;
+        }
     }
     wv::lds_sync();
     if (P.multi) {
@@ -182,8 +198,11 @@ __device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const
         float dd = 0.f;
         if (P.multi) {
             const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-            float e = l < P.gdim ? bb[BLOCK_DIM * (l / 3) + l % 3] - dgl : 0.f;
-            dd = wv::sum_row0(e * e);
+            float agl = 0.f;
+            if (l < 3 * P.nb) agl = bb[BLOCK_DIM * (l / 3) + l % 3];
+            else if (l < P.gdim) { int t = l - 3 * P.nb; agl = t == 0 ? tip[0] : (t == 1 ? tip[1] : (t == 2 ? tip[2] : closeness)); }
+            float e = l < P.gdim ? agl - dgl : 0.f;
+            dd = wv::sum_rows<2>(e * e);   /* goal_dim <= 19: lanes of the first two rows */
         } else {
 #pragma unroll
             for (int a = 0; a < 3; a++) { float e = agv[a] - g[a]; dd += e * e; }
@@ -615,7 +634,8 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
             for (int a = 7; a < 13; a++) o[a] = 0.f;
         }
         int order[5] = {0, 1, 2, 3, 4};
-        int level = P.nb - 1, moved = (1 << P.nb) - 1;
+        /* sub_goal_ind = -1 after reset (kuka_multi_step_base_env.py:248-249): the last sub-goal */
+        int level = (P.grip_goal && P.decomposition) ? 2 * P.nb - 1 : P.nb - 1, moved = (1 << P.nb) - 1;
         if (P.task == PMG_TASK_BLOCK_STACK) {
             if (P.random_order)
                 for (int i = P.nb - 1; i >= 1; i--) {

@@ -88,22 +88,22 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
     return hipGetLastError();
 }
 /* set_sub_goal (kuka_multi_step_base_env.py:154-177): new level for the masked envs, desired_goal refreshed in
- * the packed output rows; one thread per (env, goal component) */
+ * the packed output rows; 32 threads per env: goal components (<= 19) + one for the level */
 __global__ void __launch_bounds__(256) pmg_k_sub_goal(pmg::EnvParams P, const unsigned char* __restrict__ mask, int level)
 {
     int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    int env = t / 16, i = t % 16;
+    int env = t / 32, i = t % 32;
     if (env >= P.n_envs || (mask != nullptr && mask[env] == 0)) return;
     float v = 0.f;
     float* cold = P.cold + (size_t)env * pmg::COLD_DIM;
-    if (i == 15) { cold[7] = (float)level; return; }
+    if (i == 31) { cold[7] = (float)level; return; }
     if (i >= P.gdim) return;
-    v = pmg::effective_goal_at_level(P, env, i, level); /* level passed in, not read back: thread 15 may not have stored it yet */
+    v = pmg::effective_goal_at_level(P, env, i, level); /* level passed in, not read back: thread 31 may not have stored it yet */
     P.out[(size_t)env * P.packed + P.odim + P.pdim + P.gdim + i] = v;
 }
 hipError_t pmg_launch_sub_goal(const pmg::EnvParams& P, const unsigned char* d_mask, int level, hipStream_t s)
 {
-    int threads = P.n_envs * 16;
+    int threads = P.n_envs * 32;
     hipLaunchKernelGGL(pmg_k_sub_goal, dim3((threads + 255) / 256), dim3(256), 0, s, P, d_mask, level);
     return hipGetLastError();
 }

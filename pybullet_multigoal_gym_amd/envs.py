@@ -37,7 +37,7 @@ class KukaVecEnv:
     def __init__(self, task='reach', num_envs=None, binary_reward=True, joint_control=False, max_episode_steps=50,
                  distance_threshold=0.05, num_block=5, random_order=True, seed=0, seed_stride=1, device=0,
                  env_index_offset=0, dtype=np.float32, task_decomposition=False, use_curriculum=False,
-                 num_goals_to_generate=1e6, _library=None):
+                 num_goals_to_generate=1e6, grip_informed_goal=False, _library=None):
         if task not in TASK_IDS:
             raise ValueError('invalid task name: {}, only support: {}'.format(task, sorted(TASK_IDS)))
         self.task = task
@@ -60,6 +60,10 @@ class KukaVecEnv:
             warnings.warn("You will need to call env.activate_curriculum_update() before your training phase, "
                           "and env.deactivate_curriculum_update() before your evaluation phase.")
         self.curriculum_update = False
+        self.grip_informed_goal = bool(grip_informed_goal)
+        if self.grip_informed_goal:   # kuka_multi_step_envs.py:13-17,158
+            assert task == 'block_stack', 'gripper informed goals are accelerated for block_stack only'
+        self.num_steps = self.num_block * (2 if self.grip_informed_goal else 1) if multi else None
         self.dtype = np.dtype(dtype)
         self._seed_stride = int(seed_stride)
         self.handle = PmgHandle(_library or default_library(), task=TASK_IDS[task], num_envs=self.num_envs,
@@ -68,7 +72,8 @@ class KukaVecEnv:
                                 device=int(device), distance_threshold=self.distance_threshold,
                                 random_order=int(bool(random_order)), seed_base=int(seed), seed_stride=int(seed_stride),
                                 env_index_offset=int(env_index_offset), task_decomposition=int(self.task_decomposition),
-                                use_curriculum=int(self.curriculum), num_goals_to_generate=int(num_goals_to_generate))
+                                use_curriculum=int(self.curriculum), num_goals_to_generate=int(num_goals_to_generate),
+                                grip_informed_goal=int(self.grip_informed_goal))
         d = self.handle.dims
         self.dims = d
         self.action_space = spaces.Box(-np.ones([d.action_dim]), np.ones([d.action_dim]))
@@ -182,18 +187,29 @@ class KukaVecEnv:
         if not self.task_decomposition:
             return None
         st = self.handle.get_state()
-        nb = self.num_block
+        nb, n = self.num_block, len(st)
+        rows = np.arange(n)
         order = st[:, 40:40 + nb].astype(int)
         targets = st[:, 48:48 + 3 * nb].reshape(-1, nb, 3)
         blocks = np.stack([st[:, 64 + 13 * b:67 + 13 * b] for b in range(nb)], axis=1)
+
+        def goal(n_at_target, grip=None):
+            g = blocks.copy()
+            for i in range(n_at_target):
+                g[rows, order[:, i]] = targets[rows, order[:, i]]
+            g = g.reshape(n, 3 * nb)
+            if grip is not None:
+                g = np.concatenate([g, grip, np.full((n, 1), 0.03, np.float32)], axis=1)
+            g = g.astype(self.dtype)
+            return g if self.batched else g[0]
+
         out = []
         for k in range(nb):
-            g = blocks.copy()
-            for i in range(k + 1):
-                rows = np.arange(len(st))
-                g[rows, order[:, i]] = targets[rows, order[:, i]]
-            g = g.reshape(len(st), 3 * nb).astype(self.dtype)
-            out.append(g if self.batched else g[0])
+            if self.grip_informed_goal:   # (pick, place) per block: kuka_multi_step_envs.py:91-111
+                out.append(goal(k, blocks[rows, order[:, k]]))
+                out.append(goal(k + 1, targets[rows, order[:, k]]))
+            else:
+                out.append(goal(k + 1))
         return out
 
     def _curriculum(self, idx):

@@ -21,7 +21,7 @@ class PmgConfig(C.Structure):
                 ('device', C.c_int32), ('distance_threshold', C.c_float), ('random_order', C.c_int32),
                 ('seed_base', C.c_uint64), ('seed_stride', C.c_uint64), ('env_index_offset', C.c_int32),
                 ('task_decomposition', C.c_int32), ('use_curriculum', C.c_int32), ('num_goals_to_generate', C.c_int32),
-                ('reserved', C.c_int32 * 4)]
+                ('grip_informed_goal', C.c_int32), ('reserved', C.c_int32 * 3)]
 
 
 class PmgDims(C.Structure):
@@ -32,7 +32,7 @@ class PmgDims(C.Structure):
 
 def make_config(task, num_envs, num_block=4, binary_reward=True, joint_control=False, max_episode_steps=50,
                 distance_threshold=0.05, seed_base=0, seed_stride=0, random_order=True, device=0, env_index_offset=0,
-                task_decomposition=False, use_curriculum=False, num_goals_to_generate=0):
+                task_decomposition=False, use_curriculum=False, num_goals_to_generate=0, grip_informed_goal=False):
     c = PmgConfig()
     c.struct_size = C.sizeof(PmgConfig)
     c.task = TASKS[task]
@@ -50,6 +50,7 @@ def make_config(task, num_envs, num_block=4, binary_reward=True, joint_control=F
     c.task_decomposition = int(task_decomposition)
     c.use_curriculum = int(use_curriculum)
     c.num_goals_to_generate = int(num_goals_to_generate)
+    c.grip_informed_goal = int(grip_informed_goal)
     return c
 
 

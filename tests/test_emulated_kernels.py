@@ -211,3 +211,52 @@ def test_emulated_rearrange_step_matches_oracle(emu_library):
     assert np.abs(o['observation'][0, 3]) == 0 and np.abs(o['observation'][0, 7]) == 0     # no gripper terms (kuka.py:245-246)
     assert np.array_equal(r, ro) and np.array_equal(d, do)
     env.close()
+
+
+@pytest.mark.parametrize('kw', [dict(task_decomposition=True), dict(use_curriculum=True), dict()])
+def test_emulated_grip_informed_goals_match_oracle(emu_library, kw):
+    """grip_informed_goal (kuka_multi_step_envs.py:75-77,91-111,143-145): goals carry the gripper-tip target and the
+    0.03 finger width; sub-goals come in (pick, place) pairs; the achieved goal appends tip xyz + finger closeness."""
+    nb = 3
+    env = _make_quiet('block_stack', emu_library, num_block=nb, seed=3, grip_informed_goal=True, **kw)
+    ora = O.OracleEnv('block_stack', 1, num_block=nb, seed_base=3, seed_stride=1, grip_informed_goal=True, **kw)
+    ora.reset()
+    o, oo = env.reset(), ora.reset()
+    assert env.dims.goal_dim == 3 * nb + 4 and o['desired_goal'].shape == (1, 13)
+    assert np.array_equal(o['desired_goal'], oo['desired_goal'])
+    assert np.abs(o['achieved_goal'] - oo['achieved_goal']).max() < 1e-6
+    st = ora.get_state()[0]
+    order = st[40:40 + nb].astype(int)
+    tgt = lambda b: st[48 + 3 * b:51 + 3 * b]
+    pos = lambda b: st[64 + 13 * b:67 + 13 * b]
+    top = order[nb - 1]
+    if kw.get('use_curriculum'):
+        lvl = env.last_curriculum_level[0]
+        assert np.array_equal(o['desired_goal'][0, 9:12], tgt(order[lvl]))                 # :143
+    else:
+        assert np.array_equal(o['desired_goal'][0, 9:12], tgt(top))                        # :76 (and sub_goals[-1])
+    assert o['desired_goal'][0, 12] == np.float32(0.03)
+    if kw.get('task_decomposition'):
+        assert env.num_steps == 2 * nb
+        subs = env.sub_goals
+        for s in range(2 * nb):
+            g = env.set_sub_goal(s)
+            ora.set_sub_goal(s)
+            assert np.array_equal(g, ora.reset(mask=np.zeros(1, bool))['desired_goal']) and np.array_equal(g, subs[s])
+            j, pick = s // 2, s % 2 == 0
+            for i in range(nb):
+                b = order[i]
+                assert np.array_equal(g[0, 3 * b:3 * b + 3], tgt(b) if (i < j if pick else i <= j) else pos(b))
+            assert np.array_equal(g[0, 9:12], pos(order[j]) if pick else tgt(order[j]))
+        with pytest.raises(Exception):
+            env.set_sub_goal(2 * nb)
+        env.set_sub_goal(0), ora.set_sub_goal(0)
+    a = np.float32([[0.2, -0.4, -1.0, 1.0]])
+    o, r, d, info = env.step(a)
+    oo, ro, do, oko = ora.step(a)
+    assert np.abs(o['desired_goal'] - oo['desired_goal']).max() < 1e-4
+    assert np.abs(o['achieved_goal'] - oo['achieved_goal']).max() < 1e-4
+    assert np.array_equal(r, ro) and np.array_equal(info['goal_achieved'], oko)
+    r2, ok2 = env._compute_reward(o['achieved_goal'], o['desired_goal'])                   # HER path with goal_dim 13
+    assert np.array_equal(r2, r) and np.array_equal(ok2, info['goal_achieved'])
+    env.close()

@@ -204,6 +204,24 @@ def test_multistep_bookkeeping_on_device(built):
     oo, ro, do, oko = ora.step(a)
     assert np.abs(o['desired_goal'] - oo['desired_goal']).max() < 1e-4 and np.array_equal(r, ro)
     env.close()
+    # grip-informed goals: (pick, place) sub-goal pairs, goal_dim 3*nb + 4
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = pmg.make_env(task='block_stack', num_envs=N, num_block=3, seed=0, seed_stride=1, task_decomposition=True,
+                           grip_informed_goal=True)
+    ora = oracle_lib.OracleEnv('block_stack', N, num_block=3, seed_base=0, seed_stride=1, task_decomposition=True,
+                               grip_informed_goal=True)
+    ora.reset()
+    o, oo = env.reset(), ora.reset()
+    assert o['desired_goal'].shape == (N, 13) and np.array_equal(o['desired_goal'], oo['desired_goal'])
+    for s_ in (0, 3, 5):
+        g = env.set_sub_goal(s_)
+        ora.set_sub_goal(s_)
+        assert np.array_equal(g, ora.reset(mask=np.zeros(N, bool))['desired_goal']) and np.array_equal(g, env.sub_goals[s_])
+    o, r, d, info = env.step(np.zeros((N, 4), np.float32))
+    oo, ro, do, oko = ora.step(np.zeros((N, 4), np.float32))
+    assert np.abs(o['achieved_goal'] - oo['achieved_goal']).max() < 1e-4 and np.array_equal(r, ro)
+    env.close()
 
 
 def test_full_size_properties_4096(built):
