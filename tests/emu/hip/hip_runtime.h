@@ -16,7 +16,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 
 static inline const char* hipGetErrorString(hipError_t) { return "emulated hip error"; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; } /* ranks of a multi-process test each pick "their" device */
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }

@@ -25,8 +25,20 @@ def _worker(rank, world, port, total, ret):
     env.reset()
     obs, r, d, info = env.step(actions[start:stop])
     packed = D.allgather_host(D.pack_outputs(env, obs, r, d, info['goal_achieved']))
+    # the library's own collective (pmg_comm_init / pmg_allgather_packed): RCCL on the GPU build, the emulator's
+    # shared-memory stand-in here -- same call sequence as bench.py --gpus N
+    D.init_rccl(env, rank, world)
+    h = env.handle
+    nbytes = total * env.dims.packed_dim * 4
+    gathered = h.device_alloc(nbytes)
+    h.allgather_packed(gathered)
+    h.sync()
+    lib_gather = np.empty((total, env.dims.packed_dim), np.float32)
+    h.download(lib_gather, gathered)
+    h.device_free(gathered)
     if rank == 0:
         np.save(ret, packed)
+        np.save(ret + '.lib.npy', lib_gather)
     env.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -52,3 +64,23 @@ def test_two_rank_shards_equal_one_unsharded_env(built, tmp_path):
     assert np.array_equal(obs['desired_goal'], oo['desired_goal'])   # per-env seeds follow the GLOBAL index
     assert np.abs(obs['observation'] - oo['observation']).max() < 2e-5
     assert np.array_equal(r, ro) and np.array_equal(done, do)
+    assert np.array_equal(np.load(ret + '.lib.npy'), packed)         # pmg_allgather_packed == the host-side gather
+
+
+def test_bench_multi_rank_control_flow(built):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), on the emulator
+    build: rendezvous, unique-id broadcast, communicator, per-step all-gather, max-over-ranks timing, one JSON line."""
+    import json
+    import subprocess
+    port = 31000 + os.getpid() % 2000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--envs-per-gpu', '1', '--lib', os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so')]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1                                           # rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['config']['global_envs'] == 2
+    assert d['value'] > 0 and abs(d['value'] - 2 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
+    assert 'cpu_baseline' not in d and d['roofline']['launches'] == 2
