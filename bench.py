@@ -116,7 +116,10 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist = None
-    if world > 1:
+    # PMG_BENCH_FORCE_DIST=1 takes the multi-rank code path (torch.distributed rendezvous, RCCL communicator,
+    # per-step all-gather) even with one rank: lets a 1-GPU box validate what the N > 1 launch will execute
+    multi = world > 1 or bool(os.environ.get('PMG_BENCH_FORCE_DIST'))
+    if multi:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -131,7 +134,7 @@ def main():
     h = env.handle
     A = env.dims.action_dim
     gathered = None
-    if world > 1:
+    if multi:
         uid = [h.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         h.comm_init(rank, world, uid[0])
@@ -154,7 +157,7 @@ def main():
         h.sync()                       # the library's stream: every kernel and the all-gather
         if 'torch' in sys.modules and sys.modules['torch'].cuda.is_initialized():
             sys.modules['torch'].cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
 
     run(0, W)
@@ -164,7 +167,7 @@ def main():
     run(W, K)
     fence()
     el = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([el], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)   # slowest rank
         el = float(tt[0])
@@ -204,7 +207,7 @@ def main():
     if gathered is not None:
         h.device_free(gathered)
     env.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
