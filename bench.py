@@ -107,6 +107,7 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--episode-steps', type=int, default=50)
+    ap.add_argument('--dense-reward', action='store_true', help='binary_reward=False (BASELINE.json configs[3] runs both)')
     ap.add_argument('--lib', default=None, help='alternative libpmg_hip.so build (kernel A/B experiments)')
     args = ap.parse_args()
 
@@ -129,7 +130,7 @@ def main():
     N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, args.episode_steps
     from pybullet_multigoal_gym_amd._lib import PmgLibrary
     env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=local_rank, seed=0, seed_stride=1,
-                       env_index_offset=rank * N, max_episode_steps=T,
+                       env_index_offset=rank * N, max_episode_steps=T, binary_reward=not args.dense_reward,
                        _library=PmgLibrary(args.lib) if args.lib else None)
     h = env.handle
     A = env.dims.action_dim
@@ -183,8 +184,9 @@ def main():
             'value': value, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': el / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': "task='%s', %d vectorised envs/GPU, random policy U(-1,1), state obs, binary reward, "
-                                   'reset every %d steps, 100 substeps/env-step' % (args.task, N, T),
+            'config': {'workload': "task='%s', %d vectorised envs/GPU, random policy U(-1,1), state obs, %s reward, "
+                                   'reset every %d steps, 100 substeps/env-step'
+                                   % (args.task, N, 'dense' if args.dense_reward else 'binary', T),
                        'global_envs': world * N, 'parallelism': 'env-shard x%d, RCCL all-gather of packed obs' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': committed_traffic(args.task, N),
