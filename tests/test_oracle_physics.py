@@ -97,3 +97,87 @@ def test_box_box_face_contact(built):
     assert np.allclose(c[:, 9], -1e-4, atol=1e-9)                 # 0.1 mm penetration
     assert sorted(map(tuple, np.round(np.abs(c[:, 0:2]), 6))) == [(0.015, 0.015)] * 4
     assert len(O.box_box([0, 0, 0.018], I, [0.015] * 3, [0, 0, -0.08], I, [0.25, 0.35, 0.08])) == 0   # beyond the 2 mm margin
+
+
+def test_cylinder_box_known_answers(built):
+    """cyl_box against configurations with closed-form answers (puck = r 0.03, half height 0.01)."""
+    I = np.eye(3).ravel()
+    table_c, table_h = [0, 0, -0.08], [0.5, 0.45, 0.08]
+    # flat on the table, 0.1 mm into it: 4 rim points of the cap, normal +z (table -> puck), depth -1e-4
+    c = O.cyl_box([0.1, -0.05, 0.0099], I, 0.03, 0.01, table_c, I, table_h)
+    assert len(c) == 4 and np.allclose(c[:, 6:9], [0, 0, 1]) and np.allclose(c[:, 9], -1e-4, atol=1e-9)
+    assert np.allclose(np.hypot(c[:, 0] - 0.1, c[:, 1] + 0.05), 0.03, atol=1e-9)       # on the cap rim
+    assert np.allclose(c[:, 0:3].mean(0)[:2], [0.1, -0.05], atol=1e-9)                 # centred support
+    # beyond the 2 mm margin: nothing
+    assert len(O.cyl_box([0.1, -0.05, 0.0125], I, 0.03, 0.01, table_c, I, table_h)) == 0
+    # side of the upright puck against a finger-sized box face: one or two points on the generator line facing
+    # the box, normal along +x (box -> puck), depth = gap
+    c = O.cyl_box([0.0424, 0.0, 0.0], I, 0.03, 0.01, [0, 0, 0], I, [0.0125, 0.005, 0.04])
+    assert 1 <= len(c) <= 2 and np.allclose(c[:, 6:9], [1, 0, 0], atol=1e-9) and np.allclose(c[:, 9], -1e-4, atol=1e-9)
+    assert np.allclose(c[:, 0], 0.0124, atol=1e-9)                                     # points on the puck surface
+    # lying on its side on the table (axis along x): line contact -> 2 points at the generator ends
+    Ry = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], float).ravel()                   # puck z -> world x
+    c = O.cyl_box([0, 0, 0.0299], Ry, 0.03, 0.01, table_c, I, table_h)
+    assert len(c) == 2 and np.allclose(c[:, 6:9], [0, 0, 1], atol=1e-9) and np.allclose(c[:, 9], -1e-4, atol=1e-8)
+    assert np.allclose(sorted(c[:, 0]), [-0.01, 0.01], atol=1e-9)
+
+
+def test_puck_slides_and_stops_with_coulomb_friction(built):
+    """Slide: mu = 1.0 (puck) x 0.05 (long table) -> deceleration mu g plus Bullet's 0.04 (1 + |v|) base damping."""
+    env = O.OracleEnv('slide', 1)
+    env.reset()
+    st = env.get_state().copy()
+    st[0, 64:67] = [-0.9, 0.0, 0.170]
+    st[0, 71:74] = [0.0, 0.5, 0.0]                     # 0.5 m/s along +y, away from the gripper
+    env.set_state(st)
+    ys, vs = [], []
+    for _ in range(3):                                  # 3 env steps = 0.6 s
+        env.step(np.zeros((1, 3), np.float32))
+        s = env.get_state()[0]
+        ys.append(s[65]); vs.append(s[72])
+    # integrate v' = -mu g - 0.04 (1 + v) v  in 2 ms steps
+    v, y, ref = 0.5, 0.0, []
+    for k in range(300):
+        v = max(0.0, v - 0.002 * (0.05 * 9.81 + 0.04 * (1 + v) * v))
+        y += 0.002 * v
+        if (k + 1) % 100 == 0:
+            ref.append((y, v))
+    for (yr, vr), yo, vo in zip(ref, ys, vs):
+        assert abs(yo - yr) < 3e-3 and abs(vo - vr) < 6e-3
+    assert abs(env.get_state()[0, 66] - 0.170) < 2e-4   # stays flat on the table
+
+
+def test_motor_error_contracts_at_the_position_gain_rate(built):
+    """POSITION_CONTROL with kp 0.03, kd 1 (kuka.py:287-290): an unsaturated joint error shrinks by (1 - kp) per
+    substep, i.e. to ~0.048 of itself over the 100 substeps of one env step."""
+    env = O.OracleEnv('reach', 1, joint_control=True)
+    env.reset()
+    q0 = env.get_state()[0, :7].copy()
+    a = np.zeros((1, 7), np.float32)
+    a[0, 0] = 1.0                                       # joint 1 target += 0.05 rad (kuka.py:205)
+    env.step(a)
+    q1 = env.get_state()[0, :7]
+    remaining = (q0[0] + 0.05 - q1[0]) / 0.05
+    assert 0.03 < remaining < 0.07                      # (1 - 0.03)^100 = 0.0476
+    assert np.abs(q1[1:] - q0[1:]).max() < 2e-3         # the other joints hold (coupling + gravity sag only)
+
+
+def test_stacked_blocks_stay_stacked_and_energy_does_not_grow(built):
+    env = O.OracleEnv('block_stack', 1, num_block=2)
+    env.reset()
+    st = env.get_state().copy()
+    st[0, 64:67] = [-0.45, 0.12, 0.175]
+    st[0, 64 + 13:67 + 13] = [-0.45, 0.12, 0.205]       # block 1 resting on block 0
+    st[0, 67:71] = st[0, 80:84] = [0, 0, 0, 1]
+    st[0, 71:77] = st[0, 84:90] = 0
+    env.set_state(st)
+    a = np.zeros((1, 4), np.float32)
+    a[0, 3] = -1
+    ke = []
+    for _ in range(5):
+        env.step(a)
+        s = env.get_state()[0]
+        ke.append(float((s[71:77] ** 2).sum() + (s[84:90] ** 2).sum()))
+    assert np.abs(s[64:67] - [-0.45, 0.12, 0.175]).max() < 5e-4
+    assert np.abs(s[77:80] - [-0.45, 0.12, 0.205]).max() < 1e-3
+    assert max(ke) < 1e-3                               # no energy injected at rest (un-warm-started PGS jitter <~ 1 cm/s)
