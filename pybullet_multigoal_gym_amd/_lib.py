@@ -14,6 +14,7 @@ DEFAULT_LIBRARY = os.path.join(_HERE, 'csrc', 'libpmg_hip.so')
 TASK_IDS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4, 'block_rearrange': 5}
 PMG_BUF_PACKED = 7
 PMG_BUF_STATE = 8
+PMG_BUF_SCHED = 9
 
 
 class PmgConfig(C.Structure):
@@ -200,6 +201,15 @@ class PmgHandle:
         p = C.c_void_p()
         self._check(self.L.lib.pmg_device_ptr(self.h, C.c_int(which), C.byref(p)))
         return p.value
+
+    def schedule(self):
+        """Launch schedule of the last step (diagnostics): dict(prone=[...], free=[...], redo=[...]) of env indices."""
+        n = self.N
+        buf = np.empty(3 + 3 * n, np.int32)
+        self.sync()
+        self.download(buf, self.device_ptr(PMG_BUF_SCHED))
+        return {'prone': buf[2:2 + buf[0]].copy(), 'free': buf[2 + n:2 + n + buf[1]].copy(),
+                'redo': buf[3 + 2 * n:3 + 2 * n + buf[2 + 2 * n]].copy()}
 
     def stream(self):
         p = C.c_void_p()

@@ -111,6 +111,7 @@ struct pmg_env {
     double ev_ms = 0.0;
     long long ev_launches = 0;
     bool ever_reset = false;
+    int packed = 1;                   /* reach: contact-free envs four per wavefront (PMG_PACKED=0 switches it off) */
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     char err[512] = "";
@@ -298,7 +299,8 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipMalloc((void**)&e->P.blocks, N * pmg::BLOCK_DIM * (nb ? nb : 1) * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.rng, N * 625 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
-    CREATE_TRY(hipMalloc((void**)&e->P.sched, (2 + 2 * N) * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&e->P.sched, (3 + 3 * N) * sizeof(int)));
+    if (const char* pk = getenv("PMG_PACKED")) e->packed = atoi(pk) != 0;
     CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->d_mask, N));
     CREATE_TRY(hipHostMalloc((void**)&e->h_packed, N * dims.packed_dim * sizeof(float)));
@@ -315,7 +317,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         CREATE_TRY(hipMemcpy(e->P.cold, cold.data(), cold.size() * sizeof(float), hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(e->P.blocks, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice));
         {   /* identity launch schedule: all envs in the contact-prone list */
-            std::vector<int> sc(2 + 2 * N, 0);
+            std::vector<int> sc(3 + 3 * N, 0);
             sc[0] = (int)N;
             for (size_t i = 0; i < N; i++) sc[2 + i] = (int)i;
             CREATE_TRY(hipMemcpy(e->P.sched, sc.data(), sc.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -384,7 +386,7 @@ int pmg_step_device(pmg_env* e, const float* d_actions)
     int i = e->ev_n++;
     HIP_TRY(e, pmg_launch_plan(e->P, d_actions, e->stream)); /* launch-order plan (13 us), outside the step-kernel timer */
     HIP_TRY(e, hipEventRecord(e->ev_a[i], e->stream));
-    HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream));
+    HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream, e->packed));
     HIP_TRY(e, hipEventRecord(e->ev_b[i], e->stream));
     return PMG_OK;
 }
@@ -441,6 +443,7 @@ int pmg_device_ptr(pmg_env* e, int which, void** d_ptr)
     switch (which) {
     case PMG_BUF_PACKED: *d_ptr = e->P.out; return PMG_OK;
     case PMG_BUF_STATE: *d_ptr = e->P.hot; return PMG_OK;
+    case PMG_BUF_SCHED: *d_ptr = e->P.sched; return PMG_OK;
     default: return fail(e, PMG_E_INVALID, "pmg_device_ptr: buffer %d is not a device buffer (use PMG_BUF_PACKED + pmg_dims offsets)", which);
     }
 }

@@ -40,7 +40,8 @@ struct EnvParams {
     float* blocks;   /* [N, BLOCK_DIM * nb] */
     unsigned* rng;   /* [N, 625] MT19937 state + index */
     float* out;      /* [N, packed]: obs | policy | ag | dg | reward | goal_achieved | done */
-    int* sched;      /* [2 + 2N]: counts of {contact-prone, other} envs, then the two env lists */
+    int* sched;      /* [3 + 3N]: counts of {contact-prone, other} envs, the two env lists, then the redo count + list
+                        of the row-packed path (pmg_packed.h) */
 #ifdef PMG_PROFILE
     long long* prof; /* per-phase wall_clock64 ticks of env 0 */
 #endif
@@ -467,6 +468,7 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
         for (int t = 0; t < tiles; t++) { n0 += cnt0[t]; n1 += cnt1[t]; }
         P.sched[0] = n0;
         P.sched[1] = n1;
+        P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the row-packed path starts empty */
     }
 }
 __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
@@ -478,11 +480,11 @@ __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
 /* ------------------------------------------------------------------ */
 /* env.step(): kuka.py:167-225 + _get_obs + _compute_reward + TimeLimit */
 template <int NB, int MAXC, bool CYL>
-__device__ __forceinline__ void step_env(const EnvParams& P, const float* actions)
+__device__ __forceinline__ void step_env(const EnvParams& P, const float* actions, int env)
 {
     __shared__ ContactLds<NB, MAXC> L;
     __shared__ LaneTabStore lcs;
-    int env = scheduled_env(P, (int)blockIdx.x), l = wv::lane();
+    int l = wv::lane();
     if (env >= P.n_envs) return;
     LaneConst c;
     load_lane_const(lcs, c);
@@ -762,4 +764,5 @@ __device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned cha
 }
 
 }  // namespace pmg
+#include "pmg_packed.h"
 #endif

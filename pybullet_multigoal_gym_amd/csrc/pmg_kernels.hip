@@ -16,7 +16,27 @@
 template <int NB, int MAXC, bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
 {
-    pmg::step_env<NB, MAXC, CYL>(P, actions);
+    pmg::step_env<NB, MAXC, CYL>(P, actions, pmg::scheduled_env(P, (int)blockIdx.x));
+}
+
+/* reach, tip control: workgroups [0, N) run the contact-prone list one env per wavefront (the slow waves get the
+ * lowest ids and start first), workgroups [N, N + N/4) run the contact-free list four envs per wavefront */
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_reach(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    const int b = (int)blockIdx.x;
+    if (b < P.n_envs) {
+        if (b >= P.sched[0]) return;
+        pmg::step_env<0, 8, false>(P, actions, P.sched[2 + b]);
+    } else {
+        pmgp::step_group(P, actions, b - P.n_envs);
+    }
+}
+/* envs the packed path gave up on (a finger reached the table although the plan said it would not) */
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    const int* redo = P.sched + 2 + 2 * P.n_envs;
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<0, 8, false>(P, actions, redo[1 + blockIdx.x]);
 }
 
 __global__ void __launch_bounds__(1024) pmg_k_plan(pmg::EnvParams P, const float* __restrict__ actions)
@@ -79,9 +99,13 @@ hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipS
     if (P.nb == 0 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     return hipGetLastError();
 }
-hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
+hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed)
 {
-    if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    if (P.nb == 0 && !P.joint_control && packed) {
+        hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs + (P.n_envs + 3) / 4), dim3(64), 0, s, P, d_actions);
+        /* mispredictions are rare; surplus workgroups of the redo grid exit on their first instruction */
+        hipLaunchKernelGGL(pmg_k_redo, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+    } else if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     else if (P.task == PMG_TASK_SLIDE) hipLaunchKernelGGL((pmg_k_step<1, 24, true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     else if (P.nb == 1) hipLaunchKernelGGL((pmg_k_step<1, 24, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     else hipLaunchKernelGGL((pmg_k_step<5, 48, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);

@@ -5,7 +5,8 @@
 #include "pmg_kernels.h"
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s);
-hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s);
+/* packed != 0: reach with tip control runs its contact-free envs four per wavefront (pmg_packed.h) */
+hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed);
 hipError_t pmg_launch_reset(const pmg::EnvParams& P, const unsigned char* d_mask, hipStream_t s);
 hipError_t pmg_launch_sub_goal(const pmg::EnvParams& P, const unsigned char* d_mask, int level, hipStream_t s);
 hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int G, float thr, int binary, float* reward,

@@ -40,6 +40,7 @@ inline float bcast(float v, int src)
     return o;
 }
 inline int bcast_i(int v, int src) { return __float_as_int(bcast(__int_as_float(v), src)); }
+inline float bcast_serial(float v, int src) { return bcast(v, src); }
 
 template <class F>
 inline float permute(float v, float fill, F srcfn)
@@ -118,4 +119,50 @@ inline unsigned long long ballot(bool p)
     return m;
 }
 }  // namespace wv
+
+/* row-packed variant (four envs per wave, one per 16-lane row): see the product header.  The fiber scheduler
+ * advances every live fiber by one barrier per pass, so rows whose control flow has diverged stay in lockstep
+ * internally as long as an exchange only touches the caller's own row -- which is all wr does. */
+namespace wr {
+inline int lane() { return (int)threadIdx.x & 15; }
+inline int row() { return ((int)threadIdx.x & 63) >> 4; }
+inline int base() { return (int)threadIdx.x & 48; }
+inline void lds_sync() { emu_barrier(); }
+template <int N>
+inline void bcastn(const float* v, int src, float* out)
+{
+    wv::exchange_put<N>(v);
+    float t[N];
+    for (int k = 0; k < N; k++) t[k] = wv::xbuf()[64 * k + base() + src];
+    wv::exchange_done();
+    for (int k = 0; k < N; k++) out[k] = t[k];
+}
+inline float bcast(float v, int src)
+{
+    float o;
+    bcastn<1>(&v, src, &o);
+    return o;
+}
+inline int bcast_i(int v, int src) { return __float_as_int(bcast(__int_as_float(v), src)); }
+inline float bcast_serial(float v, int src) { return bcast(v, src); }
+template <int N>
+inline float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }
+template <int N>
+inline float row_shl(float v, float fill) { return wv::row_shl<N>(v, fill); }
+inline float row_sum(float v) { return wv::row_sum(v); }
+inline float row_max(float v) { return wv::row_max(v); }
+inline float sum_row0(float v) { return wv::row_sum(v); }
+inline float max_row0(float v) { return wv::row_max(v); }
+inline unsigned long long ballot(bool p)
+{
+    float f = p ? 1.f : 0.f;
+    wv::exchange_put<1>(&f);
+    unsigned long long m = 0;
+    for (int k = 0; k < 16; k++)
+        if (wv::xbuf()[base() + k] != 0.f) m |= 1ull << k;
+    wv::exchange_done();
+    return m;
+}
+inline void opaque(int& i) { (void)i; }
+}  // namespace wr
 #endif

@@ -260,3 +260,34 @@ def test_emulated_grip_informed_goals_match_oracle(emu_library, kw):
     r2, ok2 = env._compute_reward(o['achieved_goal'], o['desired_goal'])                   # HER path with goal_dim 13
     assert np.array_equal(r2, r) and np.array_equal(ok2, info['goal_achieved'])
     env.close()
+
+
+def test_emulated_row_packed_reach_and_redo(emu_library):
+    """Four envs per wavefront for the contact-free reach envs (pmg_packed.h): 6 envs = one full wave + one with
+    two live rows; then a misprediction -- an env whose plan entry says 'away from the table' while its fingers
+    are 7 mm inside it -- must be caught by the per-substep predicate and recomputed by pmg_k_redo."""
+    N = 6
+    env = pmg.make_env(task='reach', num_envs=N, seed=3, seed_stride=1, _library=emu_library)
+    ora = O.OracleEnv('reach', N, seed_base=3, seed_stride=1)
+    ora.reset()
+    env.reset(), ora.reset()
+    rs = np.random.RandomState(5)
+    a = rs.uniform(-1, 1, (N, 3)).astype(np.float32)
+    o, r, d, _ = env.step(a)
+    oo, ro, do, _ = ora.step(a)
+    sch = env.handle.schedule()
+    assert len(sch['prone']) == 0 and sorted(sch['free']) == list(range(N)) and len(sch['redo']) == 0
+    assert np.abs(o['observation'] - oo['observation']).max() < 2e-5 and np.array_equal(r, ro)
+    assert np.abs(env.get_state() - ora.get_state()).max() < 2e-5
+    st = ora.get_state().copy()
+    q_low, _ = O.ik(st[1, :9].astype(float), [-0.52, 0.0, 0.168])
+    st[1, :7] = q_low[:7]; st[1, 9:18] = 0; st[1, 18:21] = [-0.52, 0, 0.30]; st[1, 21:28] = q_low[:7]
+    env.set_state(st), ora.set_state(st)
+    o, r, d, _ = env.step(np.zeros((N, 3), np.float32))
+    oo, ro, do, _ = ora.step(np.zeros((N, 3), np.float32))
+    sch = env.handle.schedule()
+    assert list(sch['redo']) == [1] and len(sch['prone']) == 0
+    assert np.abs(o['observation'] - oo['observation']).max() < 2e-5
+    assert np.abs(env.get_state() - ora.get_state()).max() < 5e-5
+    assert oo['observation'][1, 2] > 0.17                      # the table pushed the fingers back out
+    env.close()

@@ -6,7 +6,7 @@
 #include <cstring>
 #include "pmg_kernels.h"
 template <int NB, int MAXC>
-__global__ void __launch_bounds__(64, 2) k_prof(pmg::EnvParams P, const float* act) { pmg::step_env<NB, MAXC, false>(P, act); }
+__global__ void __launch_bounds__(64, 2) k_prof(pmg::EnvParams P, const float* act) { pmg::step_env<NB, MAXC, false>(P, act, pmg::scheduled_env(P, (int)blockIdx.x)); }
 int main(int argc, char** argv)
 {
     int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push
@@ -23,7 +23,7 @@ int main(int argc, char** argv)
     for (int i = 0; i < N; i++) { for (int d = 0; d < 9; d++) hot[i * 32 + d] = q0[d]; hot[i*32+18] = -0.52f; hot[i*32+19] = 0; hot[i*32+20] = zt; hot[i*32+28] = 0.035f;
         blk[i*13+0] = -0.45f; blk[i*13+1] = 0.1f; blk[i*13+2] = 0.175f; blk[i*13+6] = 1.f; }
     hipMalloc(&P.hot, hot.size()*4); hipMalloc(&P.cold, N*16*4); hipMalloc(&P.goal, goal.size()*4); hipMalloc(&P.blocks, blk.size()*4); hipMalloc(&P.out, (size_t)N*P.packed*4);
-    { std::vector<int> sc(2 + 2 * N, 0); sc[1] = N; for (int i = 0; i < N; i++) sc[2 + N + i] = i; hipMalloc(&P.sched, sc.size()*4); hipMemcpy(P.sched, sc.data(), sc.size()*4, hipMemcpyHostToDevice); }
+    { std::vector<int> sc(3 + 3 * N, 0); sc[1] = N; for (int i = 0; i < N; i++) sc[2 + N + i] = i; hipMalloc(&P.sched, sc.size()*4); hipMemcpy(P.sched, sc.data(), sc.size()*4, hipMemcpyHostToDevice); }
     hipMalloc(&P.prof, 16*8); hipMemset(P.prof, 0, 16*8);
     float* dact; hipMalloc(&dact, act.size()*4); hipMemcpy(dact, act.data(), act.size()*4, hipMemcpyHostToDevice);
     hipMemcpy(P.hot, hot.data(), hot.size()*4, hipMemcpyHostToDevice); hipMemcpy(P.blocks, blk.data(), blk.size()*4, hipMemcpyHostToDevice); hipMemset(P.goal, 0, goal.size()*4);
