@@ -19,17 +19,15 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParam
     pmg::step_env<NB, MAXC, CYL>(P, actions, pmg::scheduled_env(P, (int)blockIdx.x));
 }
 
-/* reach, tip control: workgroups [0, N) run the contact-prone list one env per wavefront (the slow waves get the
- * lowest ids and start first), workgroups [N, N + N/4) run the contact-free list four envs per wavefront */
+/* reach, tip control: workgroups [0, n_prone) run the contact-prone list one env per wavefront (the slow waves get the
+ * lowest ids and start first), the next ceil(n_free / 4) run the contact-free list four envs per wavefront; the
+ * grid is sized for the worst case (N) and its surplus workgroups, all at the END of the dispatch order so that they
+ * cannot unbalance the placement of the real ones, exit on their first instruction */
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_reach(pmg::EnvParams P, const float* __restrict__ actions)
 {
-    const int b = (int)blockIdx.x;
-    if (b < P.n_envs) {
-        if (b >= P.sched[0]) return;
-        pmg::step_env<0, 8, false>(P, actions, P.sched[2 + b]);
-    } else {
-        pmgp::step_group(P, actions, b - P.n_envs);
-    }
+    const int b = (int)blockIdx.x, n0 = P.sched[0];
+    if (b < n0) pmg::step_env<0, 8, false>(P, actions, P.sched[2 + b]);
+    else pmgp::step_group(P, actions, b - n0);
 }
 /* envs the packed path gave up on (a finger reached the table although the plan said it would not) */
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo(pmg::EnvParams P, const float* __restrict__ actions)
@@ -102,7 +100,7 @@ hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipS
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed)
 {
     if (P.nb == 0 && !P.joint_control && packed) {
-        hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs + (P.n_envs + 3) / 4), dim3(64), 0, s, P, d_actions);
+        hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs), dim3(64), 0, s, P, d_actions); /* n_prone + ceil(n_free/4) <= N */
         /* mispredictions are rare; surplus workgroups of the redo grid exit on their first instruction */
         hipLaunchKernelGGL(pmg_k_redo, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     } else if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);

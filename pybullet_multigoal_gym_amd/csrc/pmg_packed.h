@@ -19,6 +19,13 @@
 namespace pmgp {
 
 using pmg::EnvParams;
+#ifdef PMG_PROFILE
+#define PMGP_T0() long long pt_ = wall_clock64()
+#define PMGP_T(i) do { long long n_ = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0 && P.prof) P.prof[i] += n_ - pt_; pt_ = wall_clock64(); } while (0)
+#else
+#define PMGP_T0() do { } while (0)
+#define PMGP_T(i) do { } while (0)
+#endif
 
 /* one 2 ms substep of a contact-free env; false = a finger reached the contact margin (caller must redo) */
 __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst& c_in, float& q, float& qd, float tau,
@@ -27,8 +34,10 @@ __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst
     const int l = wr::lane();
     LaneConst c = c_in;
     wr::opaque(c.col); /* keep the LDS constant reads inside the loop (no 40-register hoist) */
+    PMGP_T0();
     Kin k;
     fk(c, q, k);
+    PMGP_T(0);
     bool low = (l == 7 || l == 8) && (pmg::finger_zmin(k.p, k.R) < P.table_c[2] + P.table_h[2] + pmg::CONTACT_MARGIN);
     if (wr::ballot(low) != 0ull) return false;
     float I10[10], minv[NJ];
@@ -37,8 +46,11 @@ __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst
 #pragma unroll
         for (int a = 0; a < 10; a++) I10[a] = 0.f;
     }
+    PMGP_T(1);
     float h = bias_torque(c, k, I10, qd);
+    PMGP_T(2);
     mass_inverse(k, I10, minv);
+    PMGP_T(3);
     float rq = l < NJ ? tau - h : 0.f;
     float qdd = 0.f;
 #pragma unroll
@@ -46,11 +58,14 @@ __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst
     qd += DT * qdd;
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
+    PMGP_T(4);
     float dv = 0.f;
     for (int it = 0; it < SOLVER_ITERS; it++) {
         nc_sweep(r, (it & 1) != 0, minv, dv);
         if (wr::max_row0(nc_residual(r)) <= RESIDUAL_THRESHOLD) break;
+        PMGP_T(6);
     }
+    PMGP_T(5);
     if (l < NJ) qd += dv;
     q += DT * qd;
     return true;
@@ -114,13 +129,16 @@ __device__ __forceinline__ void step_group(const EnvParams& P, const float* acti
         float t = ee[a] + act[a] * 0.01f;
         ee[a] = fminf(fmaxf(t, P.ee_lo[a]), P.ee_hi[a]);
     }
+    PMGP_T0();
     float qik = ik_solve(c, q, ee);                    /* kuka.py:214 */
+    PMGP_T(7);
     if (l < 7) { mtarget = qik; mimp = ARM_FORCE * PHYSICS_DT; } /* kuka.py:282-290 */
     bool ok = true;
     for (int s = 0; s < SIM_STEPS && ok; s++) {        /* kuka.py:223-225 */
         float tau = -c.jdamp() * qd;                   /* joint damping latched per stepSimulation */
         for (int ss = 0; ss < SUBSTEPS && ok; ss++) ok = substep_free(P, c, q, qd, tau, mtarget, mimp);
     }
+    PMGP_T(8);
     if (!have) return;
     if (!ok) {                                         /* mispredicted: leave the state untouched, queue the env for pmg_k_redo */
         if (l == 0) {

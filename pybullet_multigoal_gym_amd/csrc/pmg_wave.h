@@ -29,8 +29,9 @@ __device__ __forceinline__ float bcast(float v, int src)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 __device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-/* a broadcast that sits on a serial dependency chain (Gauss-Seidel visits): same thing here */
-__device__ __forceinline__ float bcast_serial(float v, int src) { return bcast(v, src); }
+/* broadcast of a compile-time lane; the one on the serial chain of the Gauss-Seidel visits */
+template <int SRC>
+__device__ __forceinline__ float bcast_c(float v) { return bcast(v, SRC); }
 
 template <int N>
 __device__ __forceinline__ void bcastn(const float* v, int src, float* out)
@@ -123,9 +124,22 @@ __device__ __forceinline__ void bcastn(const float* v, int src, float* out)
 #pragma unroll
     for (int k = 0; k < N; k++) out[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v[k])));
 }
-/* broadcast on a serial dependency chain (Gauss-Seidel visits).  Measured: four v_readlane + selects are SLOWER
- * than the LDS crossbar here (1.33 vs 1.24 ms per contact-free batched step), so it is the same ds_bpermute */
-__device__ __forceinline__ float bcast_serial(float v, int src) { return bcast(v, src); }
+/* broadcast of a COMPILE-TIME row lane to the lanes that hold DoFs (0..11 of the row), for the one value that
+ * sits on the serial chain of every Gauss-Seidel visit: a quad broadcast, then the source quad rotated into the
+ * other quads with bank-masked DPP moves -- 3 dependent VALU operations (~25 cycles) instead of an LDS crossbar
+ * round trip (~120).  (Four v_readlane + selects measured SLOWER than ds_bpermute.)  Quad 3 is not written. */
+template <int SRC>
+__device__ __forceinline__ float bcast_c(float v)
+{
+    constexpr int d = SRC & 3, Q = SRC >> 2;
+    const int q0 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), d | (d << 2) | (d << 4) | (d << 6), 0xF, 0xF, false);
+    int r = q0;
+    /* quad (Q + k) & 3 takes the source quad's copy through row_ror:4k; lanes 12..15 of a row hold nothing */
+    if (((Q + 1) & 3) != 3) r = __builtin_amdgcn_update_dpp(r, q0, 0x124, 0xF, 1 << ((Q + 1) & 3), false);
+    if (((Q + 2) & 3) != 3) r = __builtin_amdgcn_update_dpp(r, q0, 0x128, 0xF, 1 << ((Q + 2) & 3), false);
+    if (((Q + 3) & 3) != 3) r = __builtin_amdgcn_update_dpp(r, q0, 0x12C, 0xF, 1 << ((Q + 3) & 3), false);
+    return __int_as_float(r);
+}
 template <int N>
 __device__ __forceinline__ float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }
 template <int N>

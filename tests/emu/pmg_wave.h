@@ -40,7 +40,8 @@ inline float bcast(float v, int src)
     return o;
 }
 inline int bcast_i(int v, int src) { return __float_as_int(bcast(__int_as_float(v), src)); }
-inline float bcast_serial(float v, int src) { return bcast(v, src); }
+template <int SRC>
+inline float bcast_c(float v) { return bcast(v, SRC); }
 
 template <class F>
 inline float permute(float v, float fill, F srcfn)
@@ -144,7 +145,8 @@ inline float bcast(float v, int src)
     return o;
 }
 inline int bcast_i(int v, int src) { return __float_as_int(bcast(__int_as_float(v), src)); }
-inline float bcast_serial(float v, int src) { return bcast(v, src); }
+template <int SRC>
+inline float bcast_c(float v) { return bcast(v, SRC); }
 template <int N>
 inline float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }
 template <int N>

@@ -7,6 +7,7 @@
 #include "pmg_kernels.h"
 template <int NB, int MAXC>
 __global__ void __launch_bounds__(64, 2) k_prof(pmg::EnvParams P, const float* act) { pmg::step_env<NB, MAXC, false>(P, act, pmg::scheduled_env(P, (int)blockIdx.x)); }
+__global__ void __launch_bounds__(64, 2) k_prof_packed(pmg::EnvParams P, const float* act) { pmgp::step_group(P, act, (int)blockIdx.x); }
 int main(int argc, char** argv)
 {
     int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push
@@ -38,6 +39,14 @@ int main(int argc, char** argv)
         printf("task %d rep %d kernel %.3f ms | ticks/substep (100MHz): fk %.0f detect %.0f dyn %.0f rows %.0f pgs %.0f | whole-step ticks: ik %lld loop %lld out %lld | nc %.0f con %.0f\n", task, rep, ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5], pr[6], pr[7], pr[8]/100., pr[9]/100.);
     }
     { long long ph[16]; hipMemcpyFromSymbol(ph, HIP_SYMBOL(pmg::g_phase), sizeof(ph)); printf("phase ticks/substep (3 reps): collide-narrow %.0f compact %.0f | R1 %.0f R2 %.0f R3 %.0f R4 %.0f\n", ph[0]/300., ph[1]/300., ph[2]/300., ph[3]/300., ph[4]/300., ph[5]/300.); }
+    if (task == 0) { // packed path: all envs on the free list, 4 per wave
+        std::vector<int> sc(3 + 3 * N, 0); sc[0] = 0; sc[1] = N; for (int i = 0; i < N; i++) sc[2 + N + i] = i;
+        hipMemcpy(P.sched, sc.data(), sc.size()*4, hipMemcpyHostToDevice);
+        hipMemcpy(P.hot, hot.data(), hot.size()*4, hipMemcpyHostToDevice);
+        for (int rep = 0; rep < 2; rep++) { hipMemset(P.prof, 0, 16*8); hipEventRecord(a); hipLaunchKernelGGL(k_prof_packed, dim3((N+3)/4), dim3(64), 0, 0, P, dact); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
+            long long pr[16]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
+            printf("PACKED kernel %.3f ms | ticks/substep: fk %.0f low+inertia %.0f bias %.0f minv %.0f qdd+rows %.0f pgs-tail %.0f pgs-iters %.0f | per wave-step: ik %.0f loop %.0f\n", ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5]/100., pr[6]/100., (double)pr[7], (double)pr[8]); }
+    }
     std::vector<float> h2(N*32); hipMemcpy(h2.data(), P.hot, h2.size()*4, hipMemcpyDeviceToHost); printf("q0 after: %f %f %f ee z %f\n", h2[1], h2[3], h2[5], h2[20]);
     return 0;
 }
