@@ -190,10 +190,11 @@ def main():
                        'global_envs': world * N, 'parallelism': 'env-shard x%d, RCCL all-gather of packed obs' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': committed_traffic(args.task, N),
-                         'kernel': 'pmg_k_step', 'kernel_ms': kernel_ms, 'launches': launches,
+                         'kernel': 'pmg_k_step_reach (+ pmg_k_redo)' if args.task == 'reach' else 'pmg_k_step<NB,MAXC,CYL>', 'kernel_ms': kernel_ms, 'launches': launches,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES[args.task],
                          'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by '
-                                 'construction (SURVEY.md 8d); the binding resource is VALU issue / dependency latency'},
+                                 'construction (SURVEY.md 8d); the binding resource is the dependency latency of that chain '
+                                 '(slowest wavefront = envs with finger-table contacts) and VALU issue, see roofline.valu'},
         }
         vi = committed_valu(args.task, N)
         if vi is not None and kernel_ms > 0:

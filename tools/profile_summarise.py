@@ -27,7 +27,7 @@ for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
         acc = {}
         for r in csv.DictReader(open(f)):
-            if not r.get('Kernel_Name', '').startswith('void pmg_k_step'):
+            if 'pmg_k_step' not in r.get('Kernel_Name', ''):
                 continue
             acc.setdefault(r['Counter_Name'], {}).setdefault(r['Dispatch_Id'], 0.0)
             acc[r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
