@@ -11,7 +11,7 @@
  * a prediction, so every substep still evaluates the exact "finger within the contact margin of the table"
  * predicate of the one-env-per-wave kernel; a row that trips it stops, writes NOTHING and queues its env on
  * the redo list, and pmg_k_redo recomputes that env from its untouched state with the full contact path.
- * Results are therefore identical to the unpacked kernel's, whatever the prediction said.
+ * Results are therefore the unpacked kernel's (to fp32 rounding), whatever the prediction said.
  */
 #ifndef PMG_PACKED_H
 #define PMG_PACKED_H

@@ -224,6 +224,49 @@ def test_multistep_bookkeeping_on_device(built):
     env.close()
 
 
+def test_row_packed_reach_schedule_and_redo(built):
+    """The packed path (four contact-free envs per wavefront) on the real device: every env of a fresh batch is on
+    the contact-free list; an env whose plan entry is wrong (tip target high, fingers 7 mm inside the table) is
+    caught by the per-substep predicate, recomputed by pmg_k_redo, and still matches the oracle; PMG_PACKED=0
+    (one env per wavefront) agrees to fp32 rounding."""
+    import os
+    N = 64
+    env, ora = _pair('reach', N)
+    env.reset(), ora.reset()
+    a = np.random.RandomState(5).uniform(-1, 1, (N, 3)).astype(np.float32)
+    o, r, d, _ = env.step(a)
+    oo, ro, do, _ = ora.step(a)
+    sch = env.handle.schedule()
+    assert len(sch['prone']) == 0 and sorted(sch['free']) == list(range(N)) and len(sch['redo']) == 0
+    assert np.abs(o['observation'] - oo['observation']).max() < 2e-5
+    st = ora.get_state().copy()
+    bad = [1, 17, 40]
+    for i in bad:
+        q_low, _ = oracle_lib.ik(st[i, :9].astype(float), [-0.52, 0.0, 0.168])
+        st[i, :7] = q_low[:7]; st[i, 9:18] = 0; st[i, 18:21] = [-0.52, 0, 0.30]; st[i, 21:28] = q_low[:7]
+    env.set_state(st), ora.set_state(st)
+    z = np.zeros((N, 3), np.float32)
+    o, r, d, _ = env.step(z)
+    oo, ro, do, _ = ora.step(z)
+    sch = env.handle.schedule()
+    assert sorted(sch['redo']) == bad and len(sch['prone']) == 0
+    assert np.abs(o['observation'] - oo['observation']).max() < 5e-5 and (oo['observation'][bad, 2] > 0.17).all()
+    packed_bits = env.get_state()
+    os.environ['PMG_PACKED'] = '0'
+    try:
+        ref = pmg.make_env(task='reach', num_envs=N, seed=0, seed_stride=1)
+    finally:
+        del os.environ['PMG_PACKED']
+    ref.reset()
+    ref.set_state(st)
+    ref.step(z)
+    # same arithmetic as one env per wavefront; the two instantiations may contract multiply-adds differently
+    diff = np.abs(ref.get_state() - packed_bits).max()
+    assert diff < 2e-5, diff
+    assert len(ref.handle.schedule()['redo']) == 0
+    ref.close(), env.close()
+
+
 def test_full_size_properties_4096(built):
     """BASELINE.json configs[1] size: determinism, per-env independence, reset idempotence."""
     N = 4096
