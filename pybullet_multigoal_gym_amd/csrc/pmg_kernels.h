@@ -12,14 +12,9 @@
 #define PMG_COLD_CONTACTS 1 /* keep the reach kernel's rare contact phases out of line (compact hot loop) */
 #endif
 
-namespace pmg {
-
-#ifdef PMG_PROFILE
-#define PMG_TICK(i) do { long long t_ = wall_clock64(); if (wv::lane() == 0 && blockIdx.x == 0) P.prof[i] += t_ - tprev; tprev = wall_clock64(); } while (0)
-#else
-#define PMG_TICK(i) do { } while (0)
-#endif
-
+/* kernel parameters: a namespace of its own, so that argument-dependent lookup never mixes the two lane-layout
+ * namespaces (pmg / pmgp) that both take it */
+namespace pmgx {
 struct EnvParams {
     int n_envs, task, nb, grasping, has_obj, joint_control, binary_reward, max_steps, in_air, random_order;
     int multi;              /* multi-block observation layout: block_stack / block_rearrange */
@@ -46,378 +41,40 @@ struct EnvParams {
     long long* prof; /* per-phase wall_clock64 ticks of env 0 */
 #endif
 };
+}  // namespace pmgx
 
-/* ------------------------------------------------------------------ */
-/* component i of the desired goal.  The multi-block tasks re-derive it from the current block poses at
- * every observation (kuka_multi_step_base_env.py:309-312): a block beyond the active curriculum level /
- * sub-goal index "is already at its goal".  cold[7] = level, goal[15] = moved-block mask.          */
-constexpr int CURR_DIM = 16;
-__device__ __forceinline__ float effective_goal_at_level(const EnvParams& P, int env, int i, int level)
-{
-    const float* g = P.goal + (size_t)env * GOAL_DIM;
-    if (!P.multi) return g[i];
-    const float* cold = P.cold + (size_t)env * COLD_DIM;
-    const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-    int b = i / 3, a = i - 3 * b;
-    if (P.task == PMG_TASK_BLOCK_STACK) {
-        /* plain / curriculum: the first level+1 blocks of the order sit at their targets.  grip-informed sub-goals
-         * come in (pick, place) pairs per block j (kuka_multi_step_envs.py:91-111): pick keeps blocks i < j, place
-         * blocks i <= j at their targets; the tail is the gripper tip target and the finger width 0.03 */
-        const bool pairs = P.grip_goal && P.decomposition;
-        const int j = pairs ? level / 2 : level;
-        const bool pick = pairs && (level % 2 == 0);
-        if (i >= 3 * P.nb) {
-            if (i == 3 * P.nb + 3) return 0.03f;
-            int bj = (int)cold[8 + j];
-            return pick ? bb[BLOCK_DIM * bj + a] : g[3 * bj + a];
-        }
-        int pos = 0;
-        for (int s = 0; s < P.nb; s++) pos = ((int)cold[8 + s] == b) ? s : pos;   /* place of block b in the stack order */
-        return (pick ? pos < j : pos <= j) ? g[i] : bb[BLOCK_DIM * b + a];
-    }
-    int moved = (int)g[15];
-    if (!((moved >> b) & 1)) return bb[BLOCK_DIM * b + a];
-    int kth = __popc((unsigned)moved & ((1u << b) - 1u));                        /* the k-th moved block takes target k */
-    return g[3 * kth + a];
-}
-__device__ __forceinline__ float effective_goal(const EnvParams& P, int env, int i)
-{
-    return effective_goal_at_level(P, env, i, P.multi ? (int)P.cold[(size_t)env * COLD_DIM + 7] : 0);
-}
+namespace pmg {
 
-/* ------------------------------------------------------------------ */
-/* observation / reward pack                                           */
-/* single-step tasks: kuka_single_step_base_env.py:193-244; robot state: kuka.py:227-256 */
-__device__ __forceinline__ void write_outputs(const EnvParams& P, int env, const LaneConst& c, float q, float qd,
-                                              int elapsed, bool with_reward)
-{
-    int l = wv::lane();
-    Kin k;
-    fk(c, q, k);
-    float tip[3], Rt[9];
-    tip_frame(k, tip, Rt);
-    /* spatial velocity of every link; lane 6 = link 7 (tip, gripper base), lane 7 = finger 1 */
-    float v[6];
-#pragma unroll
-    for (int a = 0; a < 6; a++) v[a] = chain_prefix(k.S[a] * qd);
-    float v6[6];
-    wv::bcastn<6>(v, 6, v6);
-    float tv[3], t[3];
-    cross3(v6, tip, t);
-    tv[0] = v6[3] + t[0]; tv[1] = v6[4] + t[1]; tv[2] = v6[5] + t[2];
-    float closeness = 0.f, fvel = 0.f;
-    if (P.grasping) {
-        /* tabs: finger frame origin -/+ 0.005 along finger y (urdf:480-494) */
-        float tab[3];
-        float sgn = l == 7 ? -0.005f : 0.005f;
-#pragma unroll
-        for (int a = 0; a < 3; a++) tab[a] = k.p[a] + k.R[3 * a + 1] * sgn;
-        float vt[3];
-        cross3(v, tab, vt);
-        float pack[4] = {tab[0], tab[1], tab[2], v[4] + vt[1]}, t1[4], t2[4];
-        wv::bcastn<4>(pack, 7, t1);
-        wv::bcastn<4>(pack, 8, t2);
-        float d[3] = {t1[0] - t2[0], t1[1] - t2[1], t1[2] - t2[2]};
-        closeness = sqrtf(dot3(d, d));
-        /* gripper base origin: link 7 + 0.055 z (urdf:390-395) */
-        float gb[3] = {tip[0] + Rt[2] * (0.055f - TIP_Z), tip[1] + Rt[5] * (0.055f - TIP_Z), tip[2] + Rt[8] * (0.055f - TIP_Z)};
-        float vb[3];
-        cross3(v6, gb, vb);
-        fvel = (v6[4] + vb[1]) - t1[3];
-    }
-    float* o = P.out + (size_t)env * P.packed;
-    const float* g = P.goal + (size_t)env * GOAL_DIM;
-    int jo = P.joint_control ? 7 : 0;
-    float* obs = o;
-    float* pol = o + P.odim;
-    float* ag = pol + P.pdim;
-    float* dg = ag + P.gdim;
-    float* tail = dg + P.gdim;
-    if (jo && l < 7) { obs[l] = q; pol[l] = q; }
-    float agv[3] = {tip[0], tip[1], tip[2]};
-    if (P.task == PMG_TASK_REACH) {
-        if (l < 3) { float x = l == 0 ? tip[0] : (l == 1 ? tip[1] : tip[2]); obs[jo + l] = x; pol[jo + l] = x; ag[l] = x; }
-    } else if (!P.multi) {
-        const float* b = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-        float bp[3] = {b[0], b[1], b[2]}, bv[3] = {b[7], b[8], b[9]}, bw[3] = {b[10], b[11], b[12]};
-        if (l == 0) {
-            float* s = obs + jo;
-            s[0] = tip[0]; s[1] = tip[1]; s[2] = tip[2];
-            s[3] = bp[0]; s[4] = bp[1]; s[5] = bp[2];
-            s[6] = closeness;
-            s[7] = tip[0] - bp[0]; s[8] = tip[1] - bp[1]; s[9] = tip[2] - bp[2];
-            s[10] = tv[0]; s[11] = tv[1]; s[12] = tv[2];
-            s[13] = fvel;
-            s[14] = tv[0] - bv[0]; s[15] = tv[1] - bv[1]; s[16] = tv[2] - bv[2];
-            s[17] = v6[0] - bw[0]; s[18] = v6[1] - bw[1]; s[19] = v6[2] - bw[2];
-            float* ps = pol + jo;
-            ps[0] = tip[0]; ps[1] = tip[1]; ps[2] = tip[2]; ps[3] = closeness;
-            ps[4] = tip[0] - bp[0]; ps[5] = tip[1] - bp[1]; ps[6] = tip[2] - bp[2];
-            ag[0] = bp[0]; ag[1] = bp[1]; ag[2] = bp[2];
-        }
-        agv[0] = bp[0]; agv[1] = bp[1]; agv[2] = bp[2];
-    } else {
-        /* block stack: kuka_multi_step_base_env.py:255-336, clipped to +-5 */
-        const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-        if (l == 0) {
-            float* s = obs + jo;
-            s[0] = tip[0]; s[1] = tip[1]; s[2] = tip[2]; s[3] = closeness;
-            s[4] = tv[0]; s[5] = tv[1]; s[6] = tv[2]; s[7] = fvel;
-            float* ps = pol + jo;
-            ps[0] = tip[0]; ps[1] = tip[1]; ps[2] = tip[2]; ps[3] = closeness;
-        }
-        if (l < P.nb) {
-            const float* b = bb + BLOCK_DIM * l;
-            float* s = obs + jo + 8 + 16 * l;
-            float* ps = pol + jo + 4 + 3 * l;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                s[a] = b[a];
-                s[3 + a] = tip[a] - b[a];
-                ps[a] = tip[a] - b[a];
-                s[10 + a] = tv[a] - b[7 + a];
-                s[13 + a] = v6[a] - b[10 + a];
-                ag[3 * l + a] = b[a];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; a++) s[6 + a] = b[3 + a];
-        }
-        if (P.grip_goal && l == 0) { /* kuka_multi_step_base_env.py:300-304 */
-            float* t = ag + 3 * P.nb;
-            t[0] = tip[0]; t[1] = tip[1]; t[2] = tip[2]; t[3] = closeness;
-        }
-    }
-    wv::lds_sync();
-    if (P.multi) {
-        for (int i = l; i < P.odim; i += 64) obs[i] = fminf(fmaxf(obs[i], -5.f), 5.f);
-        for (int i = l; i < P.pdim; i += 64) pol[i] = fminf(fmaxf(pol[i], -5.f), 5.f);
-    }
-    float dgl = l < P.gdim ? effective_goal(P, env, l) : 0.f;
-    if (l < P.gdim) dg[l] = dgl;
-    if (with_reward) {
-        /* _compute_reward: d = ||ag - dg||, binary -(d > thr) as float32 or dense -d */
-        float dd = 0.f;
-        if (P.multi) {
-            const float* bb = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-            float agl = 0.f;
-            if (l < 3 * P.nb) agl = bb[BLOCK_DIM * (l / 3) + l % 3];
-            else if (l < P.gdim) { int t = l - 3 * P.nb; agl = t == 0 ? tip[0] : (t == 1 ? tip[1] : (t == 2 ? tip[2] : closeness)); }
-            float e = l < P.gdim ? agl - dgl : 0.f;
-            dd = wv::sum_rows<2>(e * e);   /* goal_dim <= 19: lanes of the first two rows */
-        } else {
-#pragma unroll
-            for (int a = 0; a < 3; a++) { float e = agv[a] - g[a]; dd += e * e; }
-        }
-        float d = sqrtf(dd);
-        bool not_achieved = d > P.thr;
-        if (l == 0) {
-            tail[0] = P.binary_reward ? (not_achieved ? -1.f : -0.f) : -d;
-            tail[1] = not_achieved ? 0.f : 1.f;
-            tail[2] = elapsed >= P.max_steps ? 1.f : 0.f;
-        }
-    } else if (l == 0) {
-        tail[0] = 0.f; tail[1] = 0.f; tail[2] = 0.f;
-    }
-}
-
-/* ------------------------------------------------------------------ */
-/* contact phases of a substep.  For the reach kernel (no free bodies) they
- * are rare (fingers at the table clip plane only), so they are kept out of
- * line there to keep the register budget of the 100-substep loop small. */
-template <int NB, int MAXC>
-__device__ __noinline__ int collide_cold(ContactLds<NB, MAXC>& L, int nb, float tcx, float tcy, float tcz, float thx, float thy,
-                                         float thz, float tmu)
-{
-    float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
-    return collide<NB, MAXC, false>(L, nb, tc, th, tmu);
-}
-/* publish (inline, from registers) what the pair / contact lanes need, then run the narrowphase */
-template <int NB, int MAXC, bool CYL>
-__device__ __forceinline__ int detect(ContactLds<NB, MAXC>& L, int nb, const Kin& k, float tcx, float tcy, float tcz, float thx,
-                                      float thy, float thz, float tmu)
-{
-    int l = wv::lane();
-    if (l == 7 || l == 8) {
-        float* f = L.fing[l - 7];
-#pragma unroll
-        for (int a = 0; a < 3; a++) f[a] = k.p[a];
-#pragma unroll
-        for (int a = 0; a < 9; a++) f[3 + a] = k.R[a];
-    }
-    if (l < NJ) {
-#pragma unroll
-        for (int a = 0; a < 6; a++) L.S[l][a] = k.S[a];
-    }
-    if (NB > 0 && l == 6) { /* gripper-base cylinder: link 7 frame shifted 0.055 along its z (urdf:390-395) */
-#pragma unroll
-        for (int a = 0; a < 3; a++) L.gbase[a] = k.p[a] + k.R[3 * a + 2] * 0.055f;
-#pragma unroll
-        for (int a = 0; a < 9; a++) L.gbase[3 + a] = k.R[a];
-    }
-    if (l < nb) quat_to_R(L.blk[l] + 3, L.blkR[l]);
-    wv::lds_sync();
-    if (PMG_COLD_CONTACTS && NB == 0) return collide_cold<NB, MAXC>(L, nb, tcx, tcy, tcz, thx, thy, thz, tmu);
-    float tc[3] = {tcx, tcy, tcz}, th[3] = {thx, thy, thz};
-    return collide<NB, MAXC, CYL>(L, nb, tc, th, tmu);
-}
-
-template <int NB, int MAXC>
-__device__ __noinline__ void build_rows_cold(ContactLds<NB, MAXC>& L, int nc)
-{
-    build_contact_rows<NB, MAXC, false>(L, nc);
-}
-template <int NB, int MAXC, bool CYL>
-__device__ __forceinline__ void prepare_rows(ContactLds<NB, MAXC>& L, const float* minv, float qd, int nc)
-{
-    int l = wv::lane();
-    if (l < NJ) {
-#pragma unroll
-        for (int j = 0; j < NJ; j++) L.minv[l][j] = minv[j];
-        L.qd[l] = qd;
-    }
-    wv::lds_sync();
-    if (PMG_COLD_CONTACTS && NB == 0) build_rows_cold<NB, MAXC>(L, nc);
-    else build_contact_rows<NB, MAXC, CYL>(L, nc);
-}
-
-/* reach: PGS iterations when finger x table contacts exist -- register-resident rows (RobotRows) */
-template <int NB, int MAXC>
-__device__ __forceinline__ void reach_contact_pgs(ContactLds<NB, MAXC>& L, int nc, NcRows& r, const float* minv_in, float& dv)
-{
-    float minv[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) minv[j] = minv_in[j];
-    RobotRows<MAXC> rr;
-    load_robot_rows(L, nc, rr);
-    for (int it = 0; it < SOLVER_ITERS; it++) {
-        nc_sweep(r, (it & 1) != 0, minv, dv);
-        float resid = robot_rows_iteration(rr, nc, dv);
-        resid = fmaxf(resid, wv::max_row0(nc_residual(r)));
-        if (resid <= RESIDUAL_THRESHOLD) break;
-    }
-}
-
-/* ------------------------------------------------------------------ */
-/* one 2 ms substep: collide, unconstrained velocities, PGS rows, integrate
- * ([BULLET-PRIOR] btMultiBodyDynamicsWorld::internalSingleStepSimulation)  */
-template <int NB, int MAXC, bool CYL>
-__device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>& L, const LaneConst& c_in, float& q, float& qd,
-                                        float tau, float mtarget, float mimp)
-{
-    int l = wv::lane();
-    const int nb = NB > 0 ? P.nb : 0;
 #ifdef PMG_PROFILE
-    long long tprev = wall_clock64();
+#define PMG_TICK(i) do { long long t_ = wall_clock64(); if (wv::lane() == 0 && blockIdx.x == 0) P.prof[i] += t_ - tprev; tprev = wall_clock64(); } while (0)
+#else
+#define PMG_TICK(i) do { } while (0)
 #endif
-    LaneConst c = c_in;
-    wv::opaque(c.col); /* keep the LDS constant reads inside the loop (no 40-register hoist) */
-    Kin k;
-    fk(c, q, k);
-    PMG_TICK(0);
-    /* contact detection; without free bodies it is skipped (wave-uniform) unless a finger is near the table */
-    int nc = 0;
-    bool low = (l == 7 || l == 8) && (finger_zmin(k.p, k.R) < P.table_c[2] + P.table_h[2] + CONTACT_MARGIN);
-    if (NB > 0 || wv::ballot(low) != 0ull)
-        nc = detect<NB, MAXC, CYL>(L, nb, k, P.table_c[0], P.table_c[1], P.table_c[2], P.table_h[0], P.table_h[1], P.table_h[2], P.table_mu);
 
-    PMG_TICK(1);
-    /* unconstrained velocity update: robot (CRBA + RNEA) ... */
-    float I10[10], minv[NJ];
-    body_inertia(c, k, I10);
-    if (l >= NJ) {
-#pragma unroll
-        for (int a = 0; a < 10; a++) I10[a] = 0.f;
-    }
-    float h = bias_torque(c, k, I10, qd);   /* bias first: its temporaries are dead before the matrix work */
-    mass_inverse(k, I10, minv);
-    float rq = l < NJ ? tau - h : 0.f;
-    float qdd = 0.f;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) qdd += minv[j] * wv::bcast(rq, j);
-    qd += DT * qdd;
-    /* ... and the free objects: gravity, Bullet's base damping and the gyroscopic term w x (I w)
-     * (zero for the isotropic cubes, not for the slide puck) */
-    if (l < nb) {
-        float* b = L.blk[l];
-        const float* Rm = L.blkR[l];
-        float kl = LINK_DAMPING * (1.f + sqrtf(dot3(b + 7, b + 7))), ka = LINK_DAMPING * (1.f + sqrtf(dot3(b + 10, b + 10)));
-        float al[3] = {-b[10] * ka, -b[11] * ka, -b[12] * ka};
-        if (CYL) {
-            float wl[3], Iw[3], gy[3], tq[3];
-            wl[0] = Rm[0] * b[10] + Rm[3] * b[11] + Rm[6] * b[12];
-            wl[1] = Rm[1] * b[10] + Rm[4] * b[11] + Rm[7] * b[12];
-            wl[2] = Rm[2] * b[10] + Rm[5] * b[11] + Rm[8] * b[12];
-#pragma unroll
-            for (int a = 0; a < 3; a++) Iw[a] = wl[a] / ObjT<CYL>::inv_inertia(a);
-            cross3(wl, Iw, gy);
-#pragma unroll
-            for (int a = 0; a < 3; a++) tq[a] = (-Iw[a] * ka - gy[a]) * ObjT<CYL>::inv_inertia(a);
-            mat3v(Rm, tq, al);
-        }
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            b[7 + a] += DT * (-b[7 + a] * kl + (a == 2 ? -GRAVITY : 0.f));
-            b[10 + a] += DT * al[a];
-        }
-    }
-    PMG_TICK(2);
-    if (nc > 0) prepare_rows<NB, MAXC, CYL>(L, minv, qd, nc);
-    PMG_TICK(3);
-    NcRows r;
-    build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
-    float dv = 0.f; /* lanes 0..8: joint velocity change; lanes 9+6b+c: component c of block b */
-    if (NB == 0) {
-        if (nc > 0) {
-            reach_contact_pgs<NB, MAXC>(L, nc, r, minv, dv);
-        } else {
-            for (int it = 0; it < SOLVER_ITERS; it++) {
-                nc_sweep(r, (it & 1) != 0, minv, dv);
-                if (wv::max_row0(nc_residual(r)) <= RESIDUAL_THRESHOLD) break;
-            }
-        }
-    } else {
-        LaneDof<NB> ld;
-        lane_dof(ld);
-        for (int it = 0; it < SOLVER_ITERS; it++) {
-            PMG_TICK(10);
-            nc_sweep(r, (it & 1) != 0, minv, dv);
-            PMG_TICK(8);
-            float resid = nc > 0 ? lds_rows_iteration(L, nc, ld, dv) : 0.f;
-            PMG_TICK(9);
-            resid = fmaxf(resid, nc_residual(r));
-            /* residuals are per lane (valid where the DoFs live): one reduction per iteration */
-            if (wv::max_all(resid) <= RESIDUAL_THRESHOLD) break;
-        }
-    }
-    PMG_TICK(4);
-    if (l < NJ) qd += dv;
-    q += DT * qd;
-    if (NB > 0) {
-        if (l >= NJ && l < NJ + 6 * nb) L.blk[(l - NJ) / 6][7 + (l - NJ) % 6] += dv;
-        wv::lds_sync();
-        if (l < nb) {
-            float* b = L.blk[l];
-#pragma unroll
-            for (int a = 0; a < 3; a++) b[a] += DT * b[7 + a];
-            /* quat <- exp(omega dt) * quat */
-            float wn = sqrtf(dot3(b + 10, b + 10));
-            float ang = wn * DT;
-            float dq[4] = {0.f, 0.f, 0.f, 1.f};
-            if (ang > 1e-12f) {
-                float sh, ch;
-                sincosf(0.5f * ang, &sh, &ch);
-                float s = sh / wn;
-                dq[0] = b[10] * s; dq[1] = b[11] * s; dq[2] = b[12] * s; dq[3] = ch;
-            }
-            float x = dq[3] * b[3] + dq[0] * b[6] + dq[1] * b[5] - dq[2] * b[4];
-            float y = dq[3] * b[4] + dq[1] * b[6] + dq[2] * b[3] - dq[0] * b[5];
-            float z = dq[3] * b[5] + dq[2] * b[6] + dq[0] * b[4] - dq[1] * b[3];
-            float w = dq[3] * b[6] - dq[0] * b[3] - dq[1] * b[4] - dq[2] * b[5];
-            float inv = 1.f / sqrtf(x * x + y * y + z * z + w * w);
-            b[3] = x * inv; b[4] = y * inv; b[5] = z * inv; b[6] = w * inv;
-        }
-        wv::lds_sync();
-    }
+using pmgx::EnvParams;
+
+}  // namespace pmg
+#define WV wv
+namespace pmg {
+#include "pmg_step_body.inc"
+}  // namespace pmg
+#undef WV
+#define WV wr
+namespace pmgp {
+using pmgx::EnvParams;
+#include "pmg_step_body.inc"
+}  // namespace pmgp
+#undef WV
+namespace pmg {
+
+/* one env per wavefront: the workgroup's LDS holds this env's contact store and the lane-constant table */
+template <int NB, int MAXC, bool CYL>
+__device__ __forceinline__ void step_env(const EnvParams& P, const float* actions, int env)
+{
+    __shared__ ContactLds<NB, MAXC> L;
+    __shared__ LaneTabStore lcs;
+    if (env >= P.n_envs) return;
+    step_env_core<NB, MAXC, CYL>(P, actions, env, L, lcs, true);
 }
 
 /* ------------------------------------------------------------------ */
@@ -428,10 +85,22 @@ __device__ __forceinline__ void substep(const EnvParams& P, ContactLds<NB, MAXC>
  * issue slots.  The mapping never changes a result (envs are independent), only who waits.     */
 __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* actions, int env)
 {
-    if (P.nb > 0 || P.joint_control) return true;         /* blocks always touch the table */
+    if (P.nb > 1 || P.joint_control) return true;         /* block_stack / rearrange and joint control: one env per wavefront */
     const float* hot = P.hot + (size_t)env * HOT_DIM;
+    const float* act = actions + (size_t)env * P.adim;
+    if (P.nb == 1) {
+        /* one free object: the packed path stores few contacts per env (pmg_packed.h); the count only grows past
+         * that when the fingers work on the object, i.e. when the tip target comes within 6.5 cm of it */
+        const float* b = P.blocks + (size_t)env * BLOCK_DIM;
+        float d2 = 0.f;
+        for (int a = 0; a < 3; a++) {
+            float t = fminf(fmaxf(hot[18 + a] + act[a] * 0.01f, P.ee_lo[a]), P.ee_hi[a]);
+            d2 += (t - b[a]) * (t - b[a]);
+        }
+        return d2 < 0.065f * 0.065f;
+    }
     float z = hot[20];                                    /* tip target: the tip is within mm of it */
-    float zn = fminf(fmaxf(z + actions[(size_t)env * P.adim + 2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
+    float zn = fminf(fmaxf(z + act[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
     return fminf(z, zn) < P.ee_lo[2] + 0.012f;
 }
 /* one 1024-thread workgroup partitions all envs (stable, no atomics): per-wave ballots, counts of
@@ -475,65 +144,6 @@ __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
 {
     int n0 = P.sched[0];
     return block < n0 ? P.sched[2 + block] : P.sched[2 + P.n_envs + (block - n0)];
-}
-
-/* ------------------------------------------------------------------ */
-/* env.step(): kuka.py:167-225 + _get_obs + _compute_reward + TimeLimit */
-template <int NB, int MAXC, bool CYL>
-__device__ __forceinline__ void step_env(const EnvParams& P, const float* actions, int env)
-{
-    __shared__ ContactLds<NB, MAXC> L;
-    __shared__ LaneTabStore lcs;
-    int l = wv::lane();
-    if (env >= P.n_envs) return;
-    LaneConst c;
-    load_lane_const(lcs, c);
-    float* hot = P.hot + (size_t)env * HOT_DIM;
-    int ll = l < NJ ? l : 0;
-    float q = hot[ll], qd = hot[9 + ll];
-    if (l >= NJ) { q = 0.f; qd = 0.f; }
-    const int nb = NB > 0 ? P.nb : 0;
-    float* gblk = P.blocks + (size_t)env * BLOCK_DIM * P.nb;
-    for (int i = l; i < BLOCK_DIM * nb; i += 64) L.blk[i / BLOCK_DIM][i % BLOCK_DIM] = gblk[i];
-#ifdef PMG_PROFILE
-    long long tprev = wall_clock64();
-#endif
-    const float* act = actions + (size_t)env * P.adim;
-    float grip = hot[28];
-    int elapsed = (int)hot[29];
-    if (P.grasping) grip = (float)(((double)act[P.adim - 1] + 1.0) * (0.035 / 2)); /* kuka.py:171 */
-    float mtarget = grip, mimp = FINGER_FORCE * PHYSICS_DT;
-    float ee[3] = {hot[18], hot[19], hot[20]};
-    float jt = l < 7 ? hot[21 + l] : 0.f;
-    if (P.joint_control) {
-        if (l < 7) jt = act[l] * 0.05f + jt; /* kuka.py:205 */
-        if (l < 7) mtarget = jt;
-    } else {
-#pragma unroll
-        for (int a = 0; a < 3; a++) {      /* kuka.py:209-212 */
-            float t = ee[a] + act[a] * 0.01f;
-            ee[a] = fminf(fmaxf(t, P.ee_lo[a]), P.ee_hi[a]);
-        }
-        float qik = ik_solve(c, q, ee);    /* kuka.py:214 */
-        if (l < 7) mtarget = qik;
-    }
-    if (l < 7) mimp = ARM_FORCE * PHYSICS_DT; /* kuka.py:282-290 */
-    wv::lds_sync();
-    PMG_TICK(5);
-    for (int s = 0; s < SIM_STEPS; s++) {  /* kuka.py:223-225 */
-        float tau = -c.jdamp() * qd;         /* joint damping latched per stepSimulation */
-        for (int ss = 0; ss < SUBSTEPS; ss++) substep<NB, MAXC, CYL>(P, L, c, q, qd, tau, mtarget, mimp);
-    }
-    PMG_TICK(6);
-    elapsed++;
-    if (l < NJ) { hot[l] = q; hot[9 + l] = qd; }
-    if (l < 3) hot[18 + l] = l == 0 ? ee[0] : (l == 1 ? ee[1] : ee[2]);
-    if (l < 7) hot[21 + l] = jt;
-    if (l == 0) { hot[28] = grip; hot[29] = (float)elapsed; hot[30] = 1.f; }
-    for (int i = l; i < BLOCK_DIM * nb; i += 64) gblk[i] = L.blk[i / BLOCK_DIM][i % BLOCK_DIM];
-    wv::lds_sync();
-    write_outputs(P, env, c, q, qd, elapsed, true);
-    PMG_TICK(7);
 }
 
 /* ------------------------------------------------------------------ */

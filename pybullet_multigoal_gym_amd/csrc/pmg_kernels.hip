@@ -93,12 +93,49 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    /* contact tasks: every env is contact-prone, the identity schedule written at create time stays valid */
-    if (P.nb == 0 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    /* block_stack / rearrange and joint control: every env runs one per wavefront, the identity schedule written at
+     * create time stays valid */
+    if (P.nb <= 1 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     return hipGetLastError();
+}
+/* one free object: workgroups [0, n_prone) one env per wavefront (gripper working on the object), then the rest
+ * four envs per wavefront (pmg_packed.h); surplus workgroups at the end of the grid exit at once */
+struct ObjLds1 { /* LDS of a one-env workgroup */
+    pmg::ContactLds<1, 24> L;
+    pmg::LaneTabStore lcs;
+};
+union ObjLds { /* a workgroup runs ONE of the two layouts: they share the allocation (4 workgroups per CU either way) */
+    ObjLds1 one;
+    pmgp::ObjLds4 four;
+};
+template <bool CYL>
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_obj4(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    __shared__ ObjLds sm;
+    const int b = (int)blockIdx.x, n0 = P.sched[0];
+    if (b < n0) pmg::step_env_core<1, 24, CYL>(P, actions, P.sched[2 + b], sm.one.L, sm.one.lcs, true);
+    else pmgp::step_group_obj<CYL>(P, actions, b - n0, sm.four);
+}
+template <bool CYL>
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    const int* redo = P.sched + 2 + 2 * P.n_envs;
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<1, 24, CYL>(P, actions, redo[1 + blockIdx.x]);
 }
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed)
 {
+    if (P.nb == 1 && !P.joint_control && packed) {
+        const int groups = P.n_envs; /* n_prone + ceil(n_free / 4) <= N */
+        if (P.task == PMG_TASK_SLIDE) {
+            hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(64), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        } else {
+            hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(64), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_redo_obj<false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        }
+        return hipGetLastError();
+    }
     if (P.nb == 0 && !P.joint_control && packed) {
         hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs), dim3(64), 0, s, P, d_actions); /* n_prone + ceil(n_free/4) <= N */
         /* mispredictions are rare; surplus workgroups of the redo grid exit on their first instruction */

@@ -18,7 +18,6 @@
 
 namespace pmgp {
 
-using pmg::EnvParams;
 #ifdef PMG_PROFILE
 #define PMGP_T0() long long pt_ = wall_clock64()
 #define PMGP_T(i) do { long long n_ = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0 && P.prof) P.prof[i] += n_ - pt_; pt_ = wall_clock64(); } while (0)
@@ -153,6 +152,38 @@ __device__ __forceinline__ void step_group(const EnvParams& P, const float* acti
     if (l < 3) hot[18 + l] = l == 0 ? ee[0] : (l == 1 ? ee[1] : ee[2]);
     if (l == 0) { hot[29] = (float)elapsed; hot[30] = 1.f; }
     write_outputs_reach(P, env, c, q, elapsed);
+}
+
+/* ---------------------------------------------------------------- */
+/* One free object (push / pick_and_place / slide), four envs per wavefront.  These kernels are bound by the
+ * LATENCY of the serial constraint solve, not by issue slots, and a one-env wavefront needs two dispatch rounds
+ * for 4096 envs; four envs per wavefront fit the batch in one round.  Each row gets its own contact store; to keep
+ * four of them (plus the lane table) under 40 KB -- four workgroups per CU -- a row holds PACKED_MAXC contacts
+ * instead of 24.  The launch-order plan keeps envs whose gripper works on the object (tip target within 8 cm of it:
+ * the only situation with more contacts) on the one-env-per-wavefront list of the same fused kernel; a substep
+ * that still finds more gives the env up exactly like a mispredicted reach env: nothing is written and
+ * pmg_k_redo_obj recomputes it with the full kernel. */
+constexpr int PACKED_MAXC = 12;
+struct ObjLds4 { /* LDS of a packed workgroup: four contact stores + the lane-constant table */
+    ContactLds<1, PACKED_MAXC> Ls[4];
+    LaneTabStore lcs;
+};
+template <bool CYL>
+__device__ __forceinline__ void step_group_obj(const EnvParams& P, const float* actions, int group, ObjLds4& sm)
+{
+    ContactLds<1, PACKED_MAXC>* Ls = sm.Ls;
+    LaneTabStore& lcs = sm.lcs;
+    const int n1 = P.sched[1];
+    if (4 * group >= n1) return;
+    const int idx = 4 * group + wr::row();
+    const bool have = idx < n1;                        /* surplus rows shadow the last env and write nothing */
+    const int env = P.sched[2 + P.n_envs + (have ? idx : n1 - 1)];
+    const bool ok = step_env_core<1, PACKED_MAXC, CYL>(P, actions, env, Ls[wr::row()], lcs, have);
+    if (have && !ok && wr::lane() == 0) {
+        int* redo = P.sched + 2 + 2 * P.n_envs;
+        int slot = atomicAdd(redo, 1);
+        redo[1 + slot] = env;
+    }
 }
 
 }  // namespace pmgp

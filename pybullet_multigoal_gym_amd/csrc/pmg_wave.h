@@ -17,6 +17,7 @@
 
 namespace wv {
 
+constexpr int LANES = 64; /* lanes that cooperate on one env */
 __device__ __forceinline__ int lane() { return (int)threadIdx.x; }
 
 /* wave-level LDS ordering: a single wavefront executes DS ops in order, the
@@ -108,6 +109,7 @@ __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
  * (solver early exits, IK iteration counts) simply diverges by row. */
 namespace wr {
 
+constexpr int LANES = 16; /* lanes that cooperate on one env */
 __device__ __forceinline__ int lane() { return (int)threadIdx.x & 15; }
 __device__ __forceinline__ int row() { return (int)threadIdx.x >> 4; }
 __device__ __forceinline__ void lds_sync() { __syncthreads(); }
@@ -148,6 +150,13 @@ __device__ __forceinline__ float row_sum(float v) { return wv::row_sum(v); }
 __device__ __forceinline__ float row_max(float v) { return wv::row_max(v); }
 __device__ __forceinline__ float sum_row0(float v) { return wv::row_sum(v); } /* "row 0" = the caller's own row */
 __device__ __forceinline__ float max_row0(float v) { return wv::row_max(v); }
+/* an env owns exactly one row here: "all lanes of the env" = the row */
+template <int NR>
+__device__ __forceinline__ float sum_rows(float v) { return wv::row_sum(v); }
+__device__ __forceinline__ float sum_all(float v) { return wv::row_sum(v); }
+__device__ __forceinline__ float max_all(float v) { return wv::row_max(v); }
+/* v is uniform over the ROW: the test stays per lane and control flow diverges by row */
+__device__ __forceinline__ bool uniform_positive(float v) { return v > 0.f; }
 /* predicate mask of the caller's row (bit i = row lane i) */
 __device__ __forceinline__ unsigned long long ballot(bool p) { return (__ballot(p) >> ((int)threadIdx.x & 48)) & 0xFFFFull; }
 __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }

@@ -12,6 +12,7 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 
 namespace wv {
+constexpr int LANES = 64;
 inline int lane() { return (int)threadIdx.x & 63; }
 inline float* xbuf() { return emu_xf + ((int)threadIdx.x >> 6) * (64 * 16); } /* per-wave exchange area */
 inline void lds_sync() { emu_barrier(); }
@@ -125,6 +126,7 @@ inline unsigned long long ballot(bool p)
  * advances every live fiber by one barrier per pass, so rows whose control flow has diverged stay in lockstep
  * internally as long as an exchange only touches the caller's own row -- which is all wr does. */
 namespace wr {
+constexpr int LANES = 16;
 inline int lane() { return (int)threadIdx.x & 15; }
 inline int row() { return ((int)threadIdx.x & 63) >> 4; }
 inline int base() { return (int)threadIdx.x & 48; }
@@ -155,6 +157,11 @@ inline float row_sum(float v) { return wv::row_sum(v); }
 inline float row_max(float v) { return wv::row_max(v); }
 inline float sum_row0(float v) { return wv::row_sum(v); }
 inline float max_row0(float v) { return wv::row_max(v); }
+template <int NR>
+inline float sum_rows(float v) { return wv::row_sum(v); }
+inline float sum_all(float v) { return wv::row_sum(v); }
+inline float max_all(float v) { return wv::row_max(v); }
+inline bool uniform_positive(float v) { return v > 0.f; }
 inline unsigned long long ballot(bool p)
 {
     float f = p ? 1.f : 0.f;
