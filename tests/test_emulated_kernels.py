@@ -291,3 +291,34 @@ def test_emulated_row_packed_reach_and_redo(emu_library):
     assert np.abs(env.get_state() - ora.get_state()).max() < 5e-5
     assert oo['observation'][1, 2] > 0.17                      # the table pushed the fingers back out
     env.close()
+
+
+def test_emulated_row_packed_object_tasks_and_overflow_redo(emu_library):
+    """push with four envs per wavefront (each row its own 12-contact store): parity with the oracle, then an env the
+    plan routes to the packed list (tip TARGET 10 cm from the block) although its closed fingers are touching the
+    block on the table -- more than 12 contacts -- must be given up and recomputed by pmg_k_redo_obj."""
+    N = 5
+    env = pmg.make_env(task='push', num_envs=N, seed=3, seed_stride=1, _library=emu_library)
+    ora = O.OracleEnv('push', N, seed_base=3, seed_stride=1)
+    ora.reset()
+    env.reset(), ora.reset()
+    a = np.random.RandomState(5).uniform(-1, 1, (N, 3)).astype(np.float32)
+    env.step(a), ora.step(a)
+    sch = env.handle.schedule()
+    assert len(sch['free']) + len(sch['prone']) == N and len(sch['free']) >= 4 and len(sch['redo']) == 0
+    se, so = env.get_state(), ora.get_state()
+    assert np.abs(se[:, :9] - so[:, :9]).max() < 2e-5 and np.abs(se[:, 64:71] - so[:, 64:71]).max() < 5e-5
+    st = so.copy()
+    tipxy = ora.reset(mask=np.zeros(N, bool))['observation'][2, :2]
+    st[2, 64:67] = [tipxy[0], tipxy[1] + 0.027, 0.175]          # block against the side of the closed fingers
+    st[2, 67:71] = [0, 0, 0, 1]; st[2, 71:77] = 0
+    st[2, 18:21] = [tipxy[0], tipxy[1] - 0.10, 0.176]           # ... while the tip target is 10+ cm away
+    env.set_state(st), ora.set_state(st)
+    z = np.zeros((N, 3), np.float32)
+    o, r, d, _ = env.step(z)
+    oo, ro, do, _ = ora.step(z)
+    sch = env.handle.schedule()
+    assert 2 in sch['free'] and list(sch['redo']) == [2]
+    se, so = env.get_state(), ora.get_state()
+    assert np.abs(se[:, :9] - so[:, :9]).max() < 5e-5 and np.abs(se[:, 64:67] - so[:, 64:67]).max() < 2e-4
+    env.close()

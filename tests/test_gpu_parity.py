@@ -267,6 +267,34 @@ def test_row_packed_reach_schedule_and_redo(built):
     ref.close(), env.close()
 
 
+def test_row_packed_object_overflow_goes_through_redo(built):
+    """push on the device, four envs per wavefront: envs the plan leaves on the packed list (tip target 10 cm from
+    the block) whose closed fingers nevertheless touch the block on the table exceed the 12-contact row store, are
+    given up and recomputed by pmg_k_redo_obj; everything still tracks the oracle."""
+    N = 64
+    env, ora = _pair('push', N)
+    o32 = oracle_lib.OracleEnv('push', N, seed_base=0, seed_stride=1, threads=8, f32=True)
+    o32.reset()
+    env.reset(), ora.reset(), o32.reset()
+    st = ora.get_state().copy()
+    tip = ora.reset(mask=np.zeros(N, bool))['observation'][:, :2]
+    bad = [3, 20, 21, 47]
+    for i in bad:
+        st[i, 64:67] = [tip[i, 0], tip[i, 1] + 0.0255, 0.175]   # 0.5 mm from the side of the closed fingers
+        st[i, 67:71] = [0, 0, 0, 1]; st[i, 71:77] = 0
+        st[i, 18:21] = [tip[i, 0], tip[i, 1] - 0.10, 0.176]
+    env.set_state(st), ora.set_state(st), o32.set_state(st)
+    z = np.zeros((N, 3), np.float32)
+    env.step(z), ora.step(z), o32.step(z)
+    sch = env.handle.schedule()
+    assert sorted(sch['redo']) == bad and set(bad) <= set(sch['free'])
+    se, so, s32 = env.get_state(), ora.get_state(), o32.get_state()
+    for cols in (slice(0, 9), slice(64, 67)):
+        err, spread = np.abs(se[:, cols] - so[:, cols]).max(1), np.abs(s32[:, cols] - so[:, cols]).max(1)
+        assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4 and err[bad].max() < 3 * spread[bad].max() + 1e-3
+    env.close()
+
+
 def test_full_size_properties_4096(built):
     """BASELINE.json configs[1] size: determinism, per-env independence, reset idempotence."""
     N = 4096
