@@ -9,6 +9,7 @@ static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 
 namespace wv {
