@@ -100,6 +100,8 @@ struct pmg_env {
     pmg::EnvParams P;
     int nb;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;       /* second queue: the full-store list of the multi-block tasks runs beside the main one */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* d_actions = nullptr;       /* staging for host-buffer pmg_step */
     unsigned char* d_mask = nullptr;
     float* h_packed = nullptr;        /* pinned */
@@ -290,6 +292,9 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     } while (0)
     CREATE_TRY(hipSetDevice(cfg->device));
     CREATE_TRY(hipStreamCreate(&e->stream));
+    CREATE_TRY(hipStreamCreate(&e->side));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     size_t N = (size_t)cfg->num_envs;
     fill_params(e);
     CREATE_TRY(hipMalloc((void**)&e->P.hot, N * pmg::HOT_DIM * sizeof(float)));
@@ -348,6 +353,9 @@ void pmg_destroy(pmg_env* e)
     if (e->h_packed) (void)hipHostFree(e->h_packed);
     if (e->h_actions) (void)hipHostFree(e->h_actions);
     for (int i = 0; i < EVENT_POOL; i++) { if (e->ev_a[i]) (void)hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) (void)hipEventDestroy(e->ev_b[i]); }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -386,7 +394,7 @@ int pmg_step_device(pmg_env* e, const float* d_actions)
     int i = e->ev_n++;
     HIP_TRY(e, pmg_launch_plan(e->P, d_actions, e->stream)); /* launch-order plan (13 us), outside the step-kernel timer */
     HIP_TRY(e, hipEventRecord(e->ev_a[i], e->stream));
-    HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream, e->packed));
+    HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream, e->packed, e->side, e->ev_fork, e->ev_join));
     HIP_TRY(e, hipEventRecord(e->ev_b[i], e->stream));
     return PMG_OK;
 }

@@ -85,19 +85,22 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
  * issue slots.  The mapping never changes a result (envs are independent), only who waits.     */
 __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* actions, int env)
 {
-    if (P.nb > 1 || P.joint_control) return true;         /* block_stack / rearrange and joint control: one env per wavefront */
+    if (P.joint_control) return true;                     /* joint control: every env on the first (full) list */
     const float* hot = P.hot + (size_t)env * HOT_DIM;
     const float* act = actions + (size_t)env * P.adim;
-    if (P.nb == 1) {
-        /* one free object: the packed path stores few contacts per env (pmg_packed.h); the count only grows past
-         * that when the fingers work on the object, i.e. when the tip target comes within 6.5 cm of it */
-        const float* b = P.blocks + (size_t)env * BLOCK_DIM;
-        float d2 = 0.f;
-        for (int a = 0; a < 3; a++) {
-            float t = fminf(fmaxf(hot[18 + a] + act[a] * 0.01f, P.ee_lo[a]), P.ee_hi[a]);
-            d2 += (t - b[a]) * (t - b[a]);
+    if (P.nb >= 1) {
+        /* free objects: the fast paths store fewer contacts per env than the full kernels (pmg_packed.h,
+         * pmg_k_step_list); the count only grows past that when the fingers work on an object, i.e. when the tip
+         * target comes within 6.5 cm of one */
+        float t[3];
+        for (int a = 0; a < 3; a++) t[a] = fminf(fmaxf(hot[18 + a] + act[a] * 0.01f, P.ee_lo[a]), P.ee_hi[a]);
+        bool near = false;
+        for (int b = 0; b < P.nb; b++) {
+            const float* p = P.blocks + ((size_t)env * P.nb + b) * BLOCK_DIM;
+            float d2 = (t[0] - p[0]) * (t[0] - p[0]) + (t[1] - p[1]) * (t[1] - p[1]) + (t[2] - p[2]) * (t[2] - p[2]);
+            near = near || d2 < 0.065f * 0.065f;
         }
-        return d2 < 0.065f * 0.065f;
+        return near;
     }
     float z = hot[20];                                    /* tip target: the tip is within mm of it */
     float zn = fminf(fmaxf(z + act[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);

@@ -93,9 +93,9 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    /* block_stack / rearrange and joint control: every env runs one per wavefront, the identity schedule written at
+    /* joint control: every env runs one per wavefront with the full contact store, the identity schedule written at
      * create time stays valid */
-    if (P.nb <= 1 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    if (!P.joint_control) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     return hipGetLastError();
 }
 /* one free object: workgroups [0, n_prone) one env per wavefront (gripper working on the object), then the rest
@@ -123,8 +123,46 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvP
     if ((int)blockIdx.x >= redo[0]) return;
     pmg::step_env<1, 24, CYL>(P, actions, redo[1 + blockIdx.x]);
 }
-hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed)
+/* several free blocks (block_stack / block_rearrange): list 0 = envs whose gripper works on a block, with the full
+ * 48-contact store; list 1 = the rest with a 30-contact store (20 KB of LDS instead of 29: 8 workgroups per CU instead
+ * of 5).  The two launches run concurrently on two streams; a list-1 env that overflows is queued for the redo pass */
+constexpr int MULTI_SMALL_MAXC = 30;
+template <int NB, int MAXC, int LIST>
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
+    __shared__ pmg::ContactLds<NB, MAXC> L;
+    __shared__ pmg::LaneTabStore lcs;
+    const int b = (int)blockIdx.x;
+    if (b >= P.sched[LIST]) return;
+    const int env = P.sched[2 + LIST * P.n_envs + b];
+    const bool ok = pmg::step_env_core<NB, MAXC, false>(P, actions, env, L, lcs, true);
+    if (!ok && threadIdx.x == 0) {
+        int* redo = P.sched + 2 + 2 * P.n_envs;
+        int slot = atomicAdd(redo, 1);
+        redo[1 + slot] = env;
+    }
+}
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_multi(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    const int* redo = P.sched + 2 + 2 * P.n_envs;
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<5, 48, false>(P, actions, redo[1 + blockIdx.x]);
+}
+hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
+                           hipEvent_t ev_fork, hipEvent_t ev_join)
+{
+    if (P.nb > 1 && !P.joint_control && packed) {
+        (void)hipEventRecord(ev_fork, s);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        hipLaunchKernelGGL((pmg_k_step_list<5, 48, 0>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+        (void)hipEventRecord(ev_join, side);
+        /* up to four blocks: 24 candidate pairs instead of 32 keep the narrowphase workspace under the row store (20 KB) */
+        if (P.nb <= 4) hipLaunchKernelGGL((pmg_k_step_list<4, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<5, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        (void)hipStreamWaitEvent(s, ev_join, 0);
+        hipLaunchKernelGGL(pmg_k_redo_multi, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        return hipGetLastError();
+    }
     if (P.nb == 1 && !P.joint_control && packed) {
         const int groups = P.n_envs; /* n_prone + ceil(n_free / 4) <= N */
         if (P.task == PMG_TASK_SLIDE) {
