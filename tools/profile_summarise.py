@@ -25,14 +25,19 @@ for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
     if not os.path.isdir(d):
         continue
     for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
-        acc = {}
+        acc, per_kernel = {}, {}
         for r in csv.DictReader(open(f)):
-            if 'pmg_k_step' not in r.get('Kernel_Name', ''):
+            if 'pmg_k_step' not in r.get('Kernel_Name', '') and 'pmg_k_redo' not in r.get('Kernel_Name', ''):
                 continue
             acc.setdefault(r['Counter_Name'], {}).setdefault(r['Dispatch_Id'], 0.0)
             acc[r['Counter_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
+            per_kernel.setdefault(r['Counter_Name'], {}).setdefault(r['Kernel_Name'], set()).add(r['Dispatch_Id'])
         for name, per in acc.items():
-            summary[name] = {'launches': len(per), 'mean_per_launch': sum(per.values()) / len(per), 'pass': os.path.basename(d)}
+            # one batched step may be several dispatches (two contact-store lists, the redo pass): per STEP = the sum
+            # over all of them divided by the dispatch count of the most frequent kernel
+            steps = max(len(v) for v in per_kernel[name].values())
+            summary[name] = {'launches': steps, 'mean_per_launch': sum(per.values()) / steps, 'pass': os.path.basename(d),
+                             'kernels': sorted(k.split('(')[0] for k in per_kernel[name])}
 json.dump(summary, open(os.path.join(dst, '%s_%s4096_pmc_summary.json' % (tag, task)), 'w'), indent=1, sort_keys=True)
 if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
     fk, wk = summary['FETCH_SIZE']['mean_per_launch'], summary['WRITE_SIZE']['mean_per_launch']
