@@ -15,7 +15,7 @@
 #include <unistd.h>
 typedef struct { char internal[128]; } ncclUniqueId;
 struct emu_comm_s {
-    char name[64];
+    char name[128];
     unsigned char* base;
     size_t bytes;
     int n, rank;
