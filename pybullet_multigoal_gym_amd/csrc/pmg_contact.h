@@ -2,7 +2,7 @@
  * pmg_contact.h -- contacts of the batched env: box-box narrowphase (one pair
  * per lane), contact/friction constraint rows staged in LDS, and the
  * sequential-impulse visit of one row executed by the whole wavefront
- * (lane = DoF: lanes 0..8 robot joints, lanes 16+8b+c component c of block b).
+ * (lane = DoF: lanes 0..8 robot joints, lanes 9+6b+c component c of block b).
  *
  * Restates, per env, what Bullet does inside stepSimulation for the pairs
  * that can touch in the reference's tasks: table x
