@@ -110,7 +110,7 @@ inline float max_all(float v)
     return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
 }
 inline void opaque(int& i) { (void)i; }
-inline bool uniform_positive(float v) { return v > 0.f; }
+inline bool uniform_positive(float v) { return bcast(v, 0) > 0.f; } /* v_readfirstlane: lane 0 decides for the wave */
 inline unsigned long long ballot(bool p)
 {
     float f = p ? 1.f : 0.f;
