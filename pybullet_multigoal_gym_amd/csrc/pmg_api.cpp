@@ -306,6 +306,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.sched, (3 + 3 * N) * sizeof(int)));
     if (const char* pk = getenv("PMG_PACKED")) e->packed = atoi(pk) != 0;
+    if (N > (size_t)pmg::PLAN_MAX_TILES * 64) e->packed = 0; /* beyond the plan kernel's reach: one env per wavefront, identity order */
     CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->d_mask, N));
     CREATE_TRY(hipHostMalloc((void**)&e->h_packed, N * dims.packed_dim * sizeof(float)));

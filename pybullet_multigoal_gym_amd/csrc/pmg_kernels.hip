@@ -95,7 +95,9 @@ hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipS
 {
     /* joint control: every env runs one per wavefront with the full contact store, the identity schedule written at
      * create time stays valid */
-    if (!P.joint_control) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    /* the single-workgroup plan covers PLAN_MAX_TILES * 64 envs; beyond that (and with joint control) the identity
+     * schedule stays and pmg_api.cpp has switched the fast paths off */
+    if (!P.joint_control && P.n_envs <= pmg::PLAN_MAX_TILES * 64) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     return hipGetLastError();
 }
 /* one free object: workgroups [0, n_prone) one env per wavefront (gripper working on the object), then the rest

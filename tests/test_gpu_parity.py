@@ -384,3 +384,19 @@ def test_full_size_contact_configs_properties(built, task, N, kw):
         assert np.abs(r1 + d).max() < 1e-5
     assert np.array_equal(i1['goal_achieved'][np.abs(d - 0.05) > 1e-4], (d <= 0.05)[np.abs(d - 0.05) > 1e-4])
     env.close()
+
+
+def test_batches_beyond_the_plan_kernel_fall_back_to_identity_order(built):
+    """65 536 envs is what the single-workgroup plan kernel partitions; a larger batch must still step EVERY env
+    (one env per wavefront, identity order)."""
+    N = 65536 + 256
+    env = pmg.make_env(task='reach', num_envs=N, seed=0, seed_stride=1)
+    env.reset()
+    s0 = env.get_state()
+    a = np.zeros((N, 3), np.float32)
+    a[:, 0] = 1.0
+    env.step(a)
+    s1 = env.get_state()
+    assert (s1[:, 29] == 1).all()                                   # every env advanced its step counter
+    assert np.allclose(s1[:, 18] - s0[:, 18], 0.01, atol=1e-6)      # ... and its tip target
+    env.close()
