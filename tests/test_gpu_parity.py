@@ -400,3 +400,41 @@ def test_batches_beyond_the_plan_kernel_fall_back_to_identity_order(built):
     assert (s1[:, 29] == 1).all()                                   # every env advanced its step counter
     assert np.allclose(s1[:, 18] - s0[:, 18], 0.01, atol=1e-6)      # ... and its tip target
     env.close()
+
+
+@pytest.mark.parametrize('task,kw', [('reach', {}), ('reach', {'binary_reward': False}), ('push', {}), ('slide', {}),
+                                     ('pick_and_place', {'binary_reward': False}), ('block_stack', {'num_block': 4}),
+                                     ('block_rearrange', {'num_block': 3})])
+def test_fast_paths_agree_with_one_env_per_wavefront(built, task, kw):
+    """PMG_PACKED=1 (four envs per wavefront / small contact stores / redo) against PMG_PACKED=0 (one env per wavefront,
+    full stores, no prediction) on the same seeds and actions: the same algorithm, so reach agrees to fp32 rounding and
+    the chaotic contact tasks to a small multiple of it over a short horizon."""
+    import os
+    N, T = 512, 12
+    def make(packed):
+        os.environ['PMG_PACKED'] = packed
+        try:
+            return pmg.make_env(task=task, num_envs=N, seed=5, seed_stride=1, **kw)
+        finally:
+            del os.environ['PMG_PACKED']
+    fast, ref = make('1'), make('0')
+    of, orf = fast.reset(), ref.reset()
+    assert np.array_equal(of['desired_goal'], orf['desired_goal']) and np.array_equal(of['observation'], orf['observation'])
+    rs = np.random.RandomState(9)
+    A = fast.dims.action_dim
+    used_fast_path = False
+    for t in range(T):
+        a = rs.uniform(-1, 1, (N, A)).astype(np.float32)
+        of, rf, df, inf = fast.step(a)
+        orf, rr, dr, inr = ref.step(a)
+        used_fast_path = used_fast_path or len(fast.handle.schedule()['free']) > N // 2
+    assert used_fast_path
+    tip = np.abs(of['observation'][:, :3] - orf['observation'][:, :3]).max(1)
+    ag = np.abs(of['achieved_goal'] - orf['achieved_goal']).max(1)
+    if task == 'reach':
+        assert tip.max() < 5e-5
+        assert np.array_equal(rf, rr) if kw.get('binary_reward', True) else np.abs(rf - rr).max() < 1e-4
+    else:
+        assert np.percentile(tip, 90) < 5e-4 and np.percentile(ag, 90) < 1e-3, (np.percentile(tip, 90), np.percentile(ag, 90))
+        assert (inf['goal_achieved'] != inr['goal_achieved']).mean() < 0.02
+    fast.close(), ref.close()
