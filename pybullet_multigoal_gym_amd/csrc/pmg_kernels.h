@@ -109,38 +109,53 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
 /* one 1024-thread workgroup partitions all envs (stable, no atomics): per-wave ballots, counts of
  * every (chunk, wave) tile in LDS, then each tile scatters at its exclusive prefix */
 constexpr int PLAN_THREADS = 1024, PLAN_MAX_TILES = 1024;
+/* class of an env for the launch order: 0 = first list (one env per wavefront, full contact store), 1 / 2 = second
+ * list (fast path).  With free objects the fast-path envs are grouped by whether the fingers are down at the table
+ * (class 1) or up (class 2): the four envs of a packed wavefront then mostly walk the same contact code paths */
+__device__ __forceinline__ int plan_class(const EnvParams& P, const float* actions, int env)
+{
+    if (contact_prone(P, actions, env)) return 0;
+    if (P.nb == 0) return 1;
+    const float* hot = P.hot + (size_t)env * HOT_DIM;
+    float z = hot[20];
+    float zn = fminf(fmaxf(z + actions[(size_t)env * P.adim + 2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
+    return fminf(z, zn) < P.ee_lo[2] + 0.012f ? 1 : 2;
+}
 __device__ __forceinline__ void plan_all(const EnvParams& P, const float* actions)
 {
-    __shared__ int cnt0[PLAN_MAX_TILES], cnt1[PLAN_MAX_TILES];
+    __shared__ int cnt0[PLAN_MAX_TILES], cnt1[PLAN_MAX_TILES], cnt2[PLAN_MAX_TILES];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = PLAN_THREADS / 64;
     const int chunks = (P.n_envs + PLAN_THREADS - 1) / PLAN_THREADS;
     const unsigned long long below = (1ull << lane) - 1ull;
     for (int c = 0; c < chunks; c++) {
         int env = c * PLAN_THREADS + tid;
-        bool valid = env < P.n_envs;
-        bool prone = valid && contact_prone(P, actions, env);
-        unsigned long long m0 = wv::ballot(prone), m1 = wv::ballot(valid && !prone);
-        if (lane == 0 && c * waves + wave < PLAN_MAX_TILES) { cnt0[c * waves + wave] = __popcll(m0); cnt1[c * waves + wave] = __popcll(m1); }
+        int cls = env < P.n_envs ? plan_class(P, actions, env) : -1;
+        unsigned long long m0 = wv::ballot(cls == 0), m1 = wv::ballot(cls == 1), m2 = wv::ballot(cls == 2);
+        if (lane == 0 && c * waves + wave < PLAN_MAX_TILES) {
+            cnt0[c * waves + wave] = __popcll(m0); cnt1[c * waves + wave] = __popcll(m1); cnt2[c * waves + wave] = __popcll(m2);
+        }
     }
     __syncthreads();
     const int tiles = chunks * waves < PLAN_MAX_TILES ? chunks * waves : PLAN_MAX_TILES;
+    int n1 = 0;
+    for (int t = 0; t < tiles; t++) n1 += cnt1[t];          /* class 2 starts behind all of class 1 in the second list */
     for (int c = 0; c < chunks; c++) {
         int tile = c * waves + wave;
         int env = c * PLAN_THREADS + tid;
-        bool valid = env < P.n_envs && tile < PLAN_MAX_TILES;
-        bool prone = valid && contact_prone(P, actions, env);
-        unsigned long long m0 = wv::ballot(prone), m1 = wv::ballot(valid && !prone);
-        int b0 = 0, b1 = 0;
-        for (int t = 0; t < tile && t < tiles; t++) { b0 += cnt0[t]; b1 += cnt1[t]; }
-        if (prone) P.sched[2 + b0 + __popcll(m0 & below)] = env;
-        else if (valid) P.sched[2 + P.n_envs + b1 + __popcll(m1 & below)] = env;
+        int cls = (env < P.n_envs && tile < PLAN_MAX_TILES) ? plan_class(P, actions, env) : -1;
+        unsigned long long m0 = wv::ballot(cls == 0), m1 = wv::ballot(cls == 1), m2 = wv::ballot(cls == 2);
+        int b0 = 0, b1 = 0, b2 = 0;
+        for (int t = 0; t < tile && t < tiles; t++) { b0 += cnt0[t]; b1 += cnt1[t]; b2 += cnt2[t]; }
+        if (cls == 0) P.sched[2 + b0 + __popcll(m0 & below)] = env;
+        else if (cls == 1) P.sched[2 + P.n_envs + b1 + __popcll(m1 & below)] = env;
+        else if (cls == 2) P.sched[2 + P.n_envs + n1 + b2 + __popcll(m2 & below)] = env;
     }
     if (tid == 0) {
-        int n0 = 0, n1 = 0;
-        for (int t = 0; t < tiles; t++) { n0 += cnt0[t]; n1 += cnt1[t]; }
+        int n0 = 0, n2 = 0;
+        for (int t = 0; t < tiles; t++) { n0 += cnt0[t]; n2 += cnt2[t]; }
         P.sched[0] = n0;
-        P.sched[1] = n1;
-        P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the row-packed path starts empty */
+        P.sched[1] = n1 + n2;
+        P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
     }
 }
 __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
