@@ -1,6 +1,7 @@
 /*
- * pmg_kernels.hip -- gfx950 kernels of the batched env: one workgroup = one
- * wavefront = one environment (grid = num_envs, block = 64).
+ * pmg_kernels.hip -- gfx950 kernels of the batched env.  A workgroup is always ONE wavefront (block = 64): it
+ * simulates one environment (lane = link / DoF) or, on the fast paths, four (one per 16-lane DPP row);
+ * pmg_k_plan decides per step which envs go where (DESIGN.md sections 3.1-3.1c).
  */
 #include <hip/hip_runtime.h>
 
@@ -8,7 +9,7 @@
 #include "pmg_launch.h"
 
 #ifndef PMG_WAVES_PER_EU
-#define PMG_WAVES_PER_EU 2 /* the path is VALU-issue bound from 2 waves/SIMD on (profiles/r01): prefer 256 VGPRs and no spills */
+#define PMG_WAVES_PER_EU 2 /* 256 VGPRs and no spills in the hot loops; 3-4 waves/SIMD (168 / 128 VGPRs, spills) measured no faster */
 #endif
 
 /* three LDS footprints: reach (no blocks), one object (push / pick_and_place / slide), block_stack (<= 5 blocks);
@@ -93,8 +94,6 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    /* joint control: every env runs one per wavefront with the full contact store, the identity schedule written at
-     * create time stays valid */
     /* the single-workgroup plan covers PLAN_MAX_TILES * 64 envs; beyond that (and with joint control) the identity
      * schedule stays and pmg_api.cpp has switched the fast paths off */
     if (!P.joint_control && P.n_envs <= pmg::PLAN_MAX_TILES * 64) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
@@ -106,7 +105,7 @@ struct ObjLds1 { /* LDS of a one-env workgroup */
     pmg::ContactLds<1, 24> L;
     pmg::LaneTabStore lcs;
 };
-union ObjLds { /* a workgroup runs ONE of the two layouts: they share the allocation (4 workgroups per CU either way) */
+union ObjLds { /* a workgroup runs ONE of the two layouts: they share the allocation (31 KB: 5 workgroups per CU either way) */
     ObjLds1 one;
     pmgp::ObjLds4 four;
 };
