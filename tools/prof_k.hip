@@ -10,20 +10,20 @@ __global__ void __launch_bounds__(64, 2) k_prof(pmg::EnvParams P, const float* a
 __global__ void __launch_bounds__(64, 2) k_prof_packed(pmg::EnvParams P, const float* act) { pmgp::step_group(P, act, (int)blockIdx.x); }
 int main(int argc, char** argv)
 {
-    int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push
+    int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push, 4 block_stack with four blocks on the table
     pmg::EnvParams P; memset(&P, 0, sizeof(P));
-    int N = argc > 3 ? atoi(argv[3]) : 4096; P.n_envs = N; P.task = task; P.nb = task == 0 ? 0 : 1; P.has_obj = task != 0; P.max_steps = 50; P.binary_reward = 1;
-    P.adim = 3; P.odim = task == 0 ? 3 : 20; P.pdim = task == 0 ? 3 : 7; P.gdim = 3; P.packed = P.odim + P.pdim + 9; P.thr = 0.05f;
+    int N = argc > 3 ? atoi(argv[3]) : 4096; P.n_envs = N; P.task = task; P.nb = task == 0 ? 0 : (task == 4 ? 4 : 1); P.multi = task == 4; P.grasping = task == 4; P.has_obj = task != 0; P.max_steps = 50; P.binary_reward = 1;
+    P.adim = task == 4 ? 4 : 3; P.odim = task == 0 ? 3 : (task == 4 ? 72 : 20); P.pdim = task == 0 ? 3 : (task == 4 ? 16 : 7); P.gdim = task == 4 ? 12 : 3; P.packed = P.odim + P.pdim + 9; P.thr = 0.05f;
     float lo[3] = {-0.67f, -0.2f, 0.175f}, hi[3] = {-0.37f, 0.2f, 0.55f}, tc[3] = {-0.52f, 0, 0.08f}, th[3] = {0.25f, 0.35f, 0.08f};
     for (int a = 0; a < 3; a++) { P.ee_lo[a] = lo[a]; P.ee_hi[a] = hi[a]; P.table_c[a] = tc[a]; P.table_h[a] = th[a]; }
     P.table_mu = 0.1f;
-    std::vector<float> hot(N * 32, 0.f), goal(N * 16, 0.f), blk(N * 13, 0.f), act(N * 3, 0.f);
+    std::vector<float> hot(N * 32, 0.f), goal(N * 16, 0.f), blk(N * 13 * 4, 0.f), act(N * 4, 0.f);
     // joint pose with the tip at z ~ 0.176 (push start pose): from the oracle's reset
     float q0[9] = {0.f, -0.4712f, 0.f, 1.9904f, 0.f, -0.6800f, 0.f, 0.035f, 0.035f};
     float zt = argc > 2 ? atof(argv[2]) : 0.176f;
     for (int i = 0; i < N; i++) { for (int d = 0; d < 9; d++) hot[i * 32 + d] = q0[d]; hot[i*32+18] = -0.52f; hot[i*32+19] = 0; hot[i*32+20] = zt; hot[i*32+28] = 0.035f;
-        blk[i*13+0] = -0.45f; blk[i*13+1] = 0.1f; blk[i*13+2] = 0.175f; blk[i*13+6] = 1.f; }
-    hipMalloc(&P.hot, hot.size()*4); hipMalloc(&P.cold, N*16*4); hipMalloc(&P.goal, goal.size()*4); hipMalloc(&P.blocks, blk.size()*4); hipMalloc(&P.out, (size_t)N*P.packed*4);
+        int nbl = task == 4 ? 4 : 1; for (int b = 0; b < nbl; b++) { float* o = &blk[(i*nbl+b)*13]; o[0] = -0.45f - 0.05f*b; o[1] = 0.1f - 0.06f*b; o[2] = 0.175f; o[6] = 1.f; } }
+    hipMalloc(&P.hot, hot.size()*4); hipMalloc(&P.cold, N*16*4); { std::vector<float> cold(N*16, 0.f); for (int i = 0; i < N; i++) { cold[i*16+7] = 3.f; for (int b = 0; b < 5; b++) cold[i*16+8+b] = (float)b; } hipMemcpy(P.cold, cold.data(), cold.size()*4, hipMemcpyHostToDevice); } hipMalloc(&P.goal, goal.size()*4); hipMalloc(&P.blocks, blk.size()*4); hipMalloc(&P.out, (size_t)N*P.packed*4);
     { std::vector<int> sc(3 + 3 * N, 0); sc[1] = N; for (int i = 0; i < N; i++) sc[2 + N + i] = i; hipMalloc(&P.sched, sc.size()*4); hipMemcpy(P.sched, sc.data(), sc.size()*4, hipMemcpyHostToDevice); }
     hipMalloc(&P.prof, 16*8); hipMemset(P.prof, 0, 16*8);
     float* dact; hipMalloc(&dact, act.size()*4); hipMemcpy(dact, act.data(), act.size()*4, hipMemcpyHostToDevice);
@@ -32,7 +32,7 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 3; rep++) {
         hipMemset(P.prof, 0, 16*8);
         hipEventRecord(a);
-        if (task == 0) hipLaunchKernelGGL((k_prof<0, 8>), dim3(N), dim3(64), 0, 0, P, dact); else hipLaunchKernelGGL((k_prof<1, 24>), dim3(N), dim3(64), 0, 0, P, dact);
+        if (task == 0) hipLaunchKernelGGL((k_prof<0, 8>), dim3(N), dim3(64), 0, 0, P, dact); else if (task == 4) hipLaunchKernelGGL((k_prof<5, 48>), dim3(N), dim3(64), 0, 0, P, dact); else hipLaunchKernelGGL((k_prof<1, 24>), dim3(N), dim3(64), 0, 0, P, dact);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         long long pr[16]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
