@@ -438,3 +438,35 @@ def test_fast_paths_agree_with_one_env_per_wavefront(built, task, kw):
         assert np.percentile(tip, 90) < 5e-4 and np.percentile(ag, 90) < 1e-3, (np.percentile(tip, 90), np.percentile(ag, 90))
         assert (inf['goal_achieved'] != inr['goal_achieved']).mean() < 0.02
     fast.close(), ref.close()
+
+
+def test_small_contact_store_overflow_goes_through_redo_multi(built):
+    """block_rearrange with five blocks pushed together into a tight row on the table, gripper far away: 20 table
+    contacts + 16 between neighbours exceed the 30-contact store of the fast list, so those envs must come back through
+    pmg_k_redo_multi and still track the oracle."""
+    import warnings
+    N, nb = 32, 5
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = pmg.make_env(task='block_rearrange', num_envs=N, num_block=nb, seed=0, seed_stride=1)
+    ora = oracle_lib.OracleEnv('block_rearrange', N, num_block=nb, seed_base=0, seed_stride=1, threads=8)
+    o32 = oracle_lib.OracleEnv('block_rearrange', N, num_block=nb, seed_base=0, seed_stride=1, threads=8, f32=True)
+    ora.reset(), o32.reset()
+    env.reset(), ora.reset(), o32.reset()
+    st = ora.get_state().copy()
+    bad = [2, 9, 30]
+    for i in bad:
+        for b in range(nb):
+            st[i, 64 + 13 * b:67 + 13 * b] = [-0.62, -0.10 + 0.0305 * b, 0.175]      # 0.5 mm gaps: inside the contact margin
+            st[i, 67 + 13 * b:71 + 13 * b] = [0, 0, 0, 1]
+            st[i, 71 + 13 * b:77 + 13 * b] = 0
+    env.set_state(st), ora.set_state(st), o32.set_state(st)
+    z = np.zeros((N, 3), np.float32)
+    env.step(z), ora.step(z), o32.step(z)
+    sch = env.handle.schedule()
+    assert set(bad) <= set(sch['free']) and sorted(sch['redo']) == bad
+    se, so, s32 = env.get_state(), ora.get_state(), o32.get_state()
+    pos = [c for b in range(nb) for c in range(64 + 13 * b, 67 + 13 * b)]
+    err, spread = np.abs(se[:, pos] - so[:, pos]).max(1), np.abs(s32[:, pos] - so[:, pos]).max(1)
+    assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4 and err[bad].max() < 3 * spread[bad].max() + 1e-3
+    env.close()

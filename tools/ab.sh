@@ -1,6 +1,7 @@
 #!/bin/bash
 # kernel A/B: bench each library build in gpurun_ab/ (plus the in-tree one) on the given tasks
 tasks=${1:-push}
+mkdir -p gpurun_ab
 for t in $tasks; do
   for lib in "" $(ls gpurun_ab/*.so 2>/dev/null); do
     args=""; [ -n "$lib" ] && args="--lib $lib"
