@@ -74,6 +74,48 @@ __global__ void __launch_bounds__(256) pmg_k_reward3(const float4* __restrict__ 
         if (ok) ok[q] = flags;
     }
 }
+/* multi-block goals (G = 3 * num_block, up to 19 with the gripper tail): a workgroup owns 256 consecutive items = one
+ * contiguous span of 256 * G floats per array.  Its threads read that span FLAT (lane = consecutive 16-byte / 4-byte
+ * words: fully coalesced whatever G is), leave the partial sums of squares of their words in LDS, and thread t then adds
+ * the G / VEC partials of item t (stride G / VEC, odd for every G here: conflict-free) and stores one reward and one
+ * flag, contiguously.  VEC = 4 when G is a multiple of 4 (block_stack-4: G = 12), else 1. */
+template <int VEC>
+__global__ void __launch_bounds__(256) pmg_k_reward_flat(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int G,
+                                                        float thr, int binary, float* __restrict__ reward,
+                                                        unsigned char* __restrict__ ok)
+{
+    __shared__ float part[256 * 19];
+    const int t = (int)threadIdx.x;
+    const int wpi = G / VEC;                                   /* words per item */
+    for (long long base = (long long)blockIdx.x * 256; base < B; base += (long long)gridDim.x * 256) {
+        const long long items = B - base < 256 ? B - base : 256;
+        const long long words = items * wpi;
+        const float* a = ag + base * G;
+        const float* d = dg + base * G;
+        for (long long w = t; w < words; w += 256) {
+            float s;
+            if (VEC == 4) {
+                float4 x = ((const float4*)a)[w], y = ((const float4*)d)[w];
+                float e0 = x.x - y.x, e1 = x.y - y.y, e2 = x.z - y.z, e3 = x.w - y.w;
+                s = (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+            } else {
+                float e = a[w] - d[w];
+                s = e * e;
+            }
+            part[w] = s;
+        }
+        __syncthreads();
+        if (t < items) {
+            float s = 0.f;
+            for (int k = 0; k < wpi; k++) s += part[t * wpi + k];
+            float dist = sqrtf(s);
+            bool na = dist > thr;
+            if (reward) reward[base + t] = binary ? (na ? -1.f : -0.f) : -dist;
+            if (ok) ok[base + t] = na ? 0 : 1;
+        }
+        __syncthreads();
+    }
+}
 /* any G, and the < 4 tail items of the G == 3 path */
 __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag, const float* __restrict__ dg, long long first,
                                                    long long B, int G, float thr, int binary, float* __restrict__ reward,
@@ -223,6 +265,14 @@ hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int 
         hipLaunchKernelGGL(pmg_k_reward3, dim3(grid), dim3(256), 0, s, (const float4*)ag, (const float4*)dg, quads, thr, binary,
                            (float4*)reward, (unsigned int*)ok);
         first = quads * 4;
+    }
+    if (G > 3 && G <= 19 && B >= 256) {
+        long long want = (B + 255) / 256;
+        unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+        bool vec4 = (G % 4 == 0) && ((((size_t)ag | (size_t)dg) & 15) == 0);
+        if (vec4) hipLaunchKernelGGL((pmg_k_reward_flat<4>), dim3(grid), dim3(256), 0, s, ag, dg, B, G, thr, binary, reward, ok);
+        else hipLaunchKernelGGL((pmg_k_reward_flat<1>), dim3(grid), dim3(256), 0, s, ag, dg, B, G, thr, binary, reward, ok);
+        first = B;
     }
     if (first < B) {
         unsigned grid = (unsigned)((B - first + 255) / 256);

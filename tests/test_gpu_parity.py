@@ -470,3 +470,26 @@ def test_small_contact_store_overflow_goes_through_redo_multi(built):
     err, spread = np.abs(se[:, pos] - so[:, pos]).max(1), np.abs(s32[:, pos] - so[:, pos]).max(1)
     assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4 and err[bad].max() < 3 * spread[bad].max() + 1e-3
     env.close()
+
+
+@pytest.mark.parametrize('kw,G', [({'num_block': 4}, 12), ({'num_block': 3}, 9), ({'num_block': 3, 'grip_informed_goal': True}, 13)])
+def test_compute_reward_batch_multi_block_goals(built, kw, G):
+    """HER relabelling batches with multi-block goal vectors go through the flat coalesced kernel (float4 words when G
+    is a multiple of 4); sizes that are not a multiple of the 256-item workgroup span exercise the ragged tail."""
+    env = pmg.make_env(task='block_stack', num_envs=4, **kw)
+    assert env.dims.goal_dim == G
+    rs = np.random.RandomState(0)
+    for B in (1000, 256, 257, 5):
+        ag = rs.uniform(-0.1, 0.1, (B, G)).astype(np.float32)
+        dg = (ag + rs.uniform(-0.03, 0.03, (B, G))).astype(np.float32)
+        r, ok = env._compute_reward(ag, dg)
+        d = np.linalg.norm(ag.astype(np.float64) - dg, axis=-1)
+        clear = np.abs(d - 0.05) > 1e-6
+        assert np.array_equal(r[clear], -(d > 0.05).astype(np.float32)[clear]) and np.array_equal(ok[clear], ~(d > 0.05)[clear])
+    env.close()
+    dense = pmg.make_env(task='block_stack', num_envs=4, binary_reward=False, **kw)
+    ag = rs.uniform(-0.1, 0.1, (777, G)).astype(np.float32)
+    dg = rs.uniform(-0.1, 0.1, (777, G)).astype(np.float32)
+    r, ok = dense._compute_reward(ag, dg)
+    assert np.abs(r + np.linalg.norm(ag.astype(np.float64) - dg, axis=-1)).max() < 1e-5
+    dense.close()
