@@ -75,3 +75,22 @@ def test_env_wrapper_shapes_and_errors_on_the_emulator(emu_library):
     env64 = pmg.make_env(task='reach', num_envs=2, dtype='float64', _library=emu_library)
     assert env64.reset()['observation'].dtype == np.float64 and env64.reset()['observation'].shape == (2, 3)
     env64.close()
+
+
+def test_integration_stub_config_matches_the_header():
+    """The ctypes struct printed in INTEGRATION.md (what a reference maintainer would paste) must stay the pmg_config of
+    include/pmg.h: same field names, same order, same size."""
+    import ctypes as C
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'INTEGRATION.md')).read()
+    ns = {'C': C}
+    exec(re.search(r"class PmgConfig\(C.Structure\):.*?\n\n", src, re.S).group(0), ns)
+    doc = ns['PmgConfig']
+    from pybullet_multigoal_gym_amd._lib import PmgConfig
+    assert C.sizeof(doc) == C.sizeof(PmgConfig) == 88
+    assert [f[0] for f in doc._fields_] == [f[0] for f in PmgConfig._fields_]
+    hdr = open(os.path.join(root, 'include', 'pmg.h')).read()
+    body = hdr[hdr.index('typedef struct pmg_config {'):hdr.index('} pmg_config;')]
+    names = re.findall(r'^\s+(?:u?int\d+_t|float)\s+(\w+)', body, re.M)
+    assert names == [f[0] for f in PmgConfig._fields_]
