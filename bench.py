@@ -26,6 +26,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver only supports dmabuf IPC: RCCL's cross-process buffer sharing needs this before any HIP/HSA init
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 # algorithmic bytes per env-step (state r+w, action, outputs)
 ALGO_BYTES = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242}
