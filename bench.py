@@ -137,11 +137,28 @@ def main():
     h = env.handle
     A = env.dims.action_dim
     gathered = None
+    host_gather = None
+    collective = 'RCCL all-gather of packed obs'
     if multi:
         uid = [h.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        h.comm_init(rank, world, uid[0])
-        gathered = h.device_alloc(world * N * env.dims.packed_dim * 4)
+        try:
+            if os.environ.get('PMG_BENCH_FORCE_COMM_FAIL'):   # test hook for the fallback below
+                raise RuntimeError('forced by PMG_BENCH_FORCE_COMM_FAIL')
+            h.comm_init(rank, world, uid[0])
+            ok = 1
+        except Exception as ex:   # noqa: BLE001 -- reported below, never silent
+            print('rank %d: RCCL communicator failed (%s)' % (rank, ex), file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            gathered = h.device_alloc(world * N * env.dims.packed_dim * 4)
+        else:
+            # every rank takes the SAME fallback, and the JSON line says so: packed rows to the host, gloo all-gather
+            collective = 'FALLBACK: RCCL init failed, host gloo all-gather of packed obs (PCIe-inclusive)'
+            mine = torch.empty((N, env.dims.packed_dim), dtype=torch.float32)
+            host_gather = (mine, [torch.empty_like(mine) for _ in range(world)])
     # synthetic random policy: a table of K+W batches of U(-1,1) float32 actions, resident in HBM
     table = np.random.RandomState(12345 + rank).uniform(-1, 1, (K + W, N, A)).astype(np.float32)
     actions = h.device_alloc(table.nbytes)
@@ -155,6 +172,10 @@ def main():
             h.step_device(actions + t * stride)
             if gathered is not None:
                 h.allgather_packed(gathered)
+            elif host_gather is not None:
+                h.sync()
+                h.download(host_gather[0].numpy(), h.device_ptr())
+                dist.all_gather(host_gather[1], host_gather[0])
 
     def fence():
         h.sync()                       # the library's stream: every kernel and the all-gather
@@ -189,7 +210,7 @@ def main():
             'config': {'workload': "task='%s', %d vectorised envs/GPU, random policy U(-1,1), state obs, %s reward, "
                                    'reset every %d steps, 100 substeps/env-step'
                                    % (args.task, N, 'dense' if args.dense_reward else 'binary', T),
-                       'global_envs': world * N, 'parallelism': 'env-shard x%d, RCCL all-gather of packed obs' % world},
+                       'global_envs': world * N, 'parallelism': 'env-shard x%d, %s' % (world, collective)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': committed_traffic(args.task, N),
                          'kernel': 'pmg_k_step_reach (+ pmg_k_redo)' if args.task == 'reach' else 'pmg_k_step<NB,MAXC,CYL>', 'kernel_ms': kernel_ms, 'launches': launches,

@@ -67,7 +67,8 @@ def test_two_rank_shards_equal_one_unsharded_env(built, tmp_path):
     assert np.array_equal(np.load(ret + '.lib.npy'), packed)         # pmg_allgather_packed == the host-side gather
 
 
-def test_bench_multi_rank_control_flow(built):
+@pytest.mark.parametrize('force_fail', [False, True])
+def test_bench_multi_rank_control_flow(built, force_fail):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), on the emulator
     build: rendezvous, unique-id broadcast, communicator, per-step all-gather, max-over-ranks timing, one JSON line."""
     import json
@@ -76,7 +77,10 @@ def test_bench_multi_rank_control_flow(built):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
            '--envs-per-gpu', '1', '--lib', os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so')]
-    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if force_fail:   # the communicator cannot be created: every rank must take the labelled host fallback together
+        env['PMG_BENCH_FORCE_COMM_FAIL'] = '1'
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1                                           # rank 0 only
@@ -84,3 +88,4 @@ def test_bench_multi_rank_control_flow(built):
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['config']['global_envs'] == 2
     assert d['value'] > 0 and abs(d['value'] - 2 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
     assert 'cpu_baseline' not in d and d['roofline']['launches'] == 2
+    assert ('FALLBACK' in d['config']['parallelism']) == force_fail
