@@ -83,11 +83,61 @@ __device__ __forceinline__ void step_env(const EnvParams& P, const float* action
  * hardware favours the OLDEST wave of a SIMD, so those envs are given the lowest workgroup ids:
  * dispatched first, one per SIMD, they run at single-wave speed from t = 0 while the rest fill the
  * issue slots.  The mapping never changes a result (envs are independent), only who waits.     */
+/* forward kinematics of ONE env by ONE thread (the plan kernel's view of an env): lowest point of either finger box
+ * and the tip position, from the joint angles -- same chain as fk() of pmg_device_body.inc, without the wave */
+__device__ inline void plan_fk(const float* q, float& finger_z, float* tip)
+{
+    float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}, p[3] = {0.f, 0.f, 0.f};
+    float R6[9], p6[3];
+    const float fh[3] = PMG_FINGER_HALF;
+    finger_z = 1e30f;
+    for (int j = 0; j < NJ; j++) {
+        if (j == 7) { for (int a = 0; a < 9; a++) R6[a] = R[a]; for (int a = 0; a < 3; a++) p6[a] = p[a]; }
+        if (j == 8) { for (int a = 0; a < 9; a++) R[a] = R6[a]; for (int a = 0; a < 3; a++) p[a] = p6[a]; } /* finger 2 hangs off link 7 too */
+        float L[9], o[3];
+        if (C_JTYPE[j] != 0) {            /* prismatic along the joint axis */
+            for (int a = 0; a < 9; a++) L[a] = C_JROT[j][a / 3][a % 3];
+            float d[3];
+            for (int r = 0; r < 3; r++) d[r] = L[3 * r] * C_JAXIS[j][0] + L[3 * r + 1] * C_JAXIS[j][1] + L[3 * r + 2] * C_JAXIS[j][2];
+            for (int a = 0; a < 3; a++) o[a] = C_JXYZ[j][a] + d[a] * q[j];
+        } else {                          /* revolute about local z */
+            float s, c;
+            sincosf(q[j], &s, &c);
+            for (int r = 0; r < 3; r++) {
+                float rx = C_JROT[j][r][0], ry = C_JROT[j][r][1];
+                L[3 * r] = rx * c + ry * s; L[3 * r + 1] = ry * c - rx * s; L[3 * r + 2] = C_JROT[j][r][2];
+                o[r] = C_JXYZ[j][r];
+            }
+        }
+        float t[3];
+        mat3v(R, o, t);
+        p[0] += t[0]; p[1] += t[1]; p[2] += t[2];
+        mat3m(R, L, R);
+        if (j >= 7) finger_z = fminf(finger_z, p[2] - (fabsf(R[6]) * fh[0] + fabsf(R[7]) * fh[1] + fabsf(R[8]) * fh[2]));
+    }
+    for (int a = 0; a < 3; a++) tip[a] = p6[a] + R6[3 * a + 2] * TIP_Z;
+}
+
 __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* actions, int env)
 {
-    if (P.joint_control) return true;                     /* joint control: every env on the first (full) list */
     const float* hot = P.hot + (size_t)env * HOT_DIM;
     const float* act = actions + (size_t)env * P.adim;
+    if (P.joint_control) {
+        /* joint targets move by up to 0.05 rad per step (kuka.py:205): with the ~0.8 m reach of the arm a finger or the
+         * tip travels at most ~4.5 cm.  Prone = a finger could get inside the contact margin of the table, or the tip
+         * within reach of a free object (6.5 cm, as under tip control) */
+        float q[NJ], fz, tip[3];
+        for (int d = 0; d < NJ; d++) q[d] = hot[d];
+        plan_fk(q, fz, tip);
+        if (fz < P.table_c[2] + P.table_h[2] + 0.045f + CONTACT_MARGIN) return true;
+        if (P.nb > 1) return true;                       /* several blocks: keep the full store under joint control */
+        for (int b = 0; b < P.nb; b++) {
+            const float* pb = P.blocks + ((size_t)env * P.nb + b) * BLOCK_DIM;
+            float d2 = (tip[0] - pb[0]) * (tip[0] - pb[0]) + (tip[1] - pb[1]) * (tip[1] - pb[1]) + (tip[2] - pb[2]) * (tip[2] - pb[2]);
+            if (d2 < 0.11f * 0.11f) return true;
+        }
+        return false;
+    }
     if (P.nb >= 1) {
         /* free objects: the fast paths store fewer contacts per env than the full kernels (pmg_packed.h,
          * pmg_k_step_list); the count only grows past that when the fingers work on an object, i.e. when the tip

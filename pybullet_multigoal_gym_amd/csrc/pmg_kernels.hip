@@ -136,28 +136,20 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    /* the single-workgroup plan covers PLAN_MAX_TILES * 64 envs; beyond that (and with joint control) the identity
-     * schedule stays and pmg_api.cpp has switched the fast paths off */
-    if (!P.joint_control && P.n_envs <= pmg::PLAN_MAX_TILES * 64) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    /* the single-workgroup plan covers PLAN_MAX_TILES * 64 envs; beyond that the identity schedule stays and
+     * pmg_api.cpp has switched the fast paths off */
+    if (P.n_envs <= pmg::PLAN_MAX_TILES * 64) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     return hipGetLastError();
 }
-/* one free object: workgroups [0, n_prone) one env per wavefront (gripper working on the object), then the rest
- * four envs per wavefront (pmg_packed.h); surplus workgroups at the end of the grid exit at once */
-struct ObjLds1 { /* LDS of a one-env workgroup */
-    pmg::ContactLds<1, 24> L;
-    pmg::LaneTabStore lcs;
-};
-union ObjLds { /* a workgroup runs ONE of the two layouts: they share the allocation (31 KB: 5 workgroups per CU either way) */
-    ObjLds1 one;
-    pmgp::ObjLds4 four;
-};
+/* one free object: the fast-path list four envs per wavefront (pmg_packed.h; 31 KB of LDS per workgroup).  The envs
+ * whose gripper works on the object run one per wavefront with the full 24-contact store in a SEPARATE launch
+ * (pmg_k_step_list<1,24,0,CYL>, 16 KB) on the side stream, so that a batch in which most envs are of that kind keeps
+ * the occupancy it had before the packing; surplus workgroups at the end of either grid exit at once */
 template <bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_obj4(pmg::EnvParams P, const float* __restrict__ actions)
 {
-    __shared__ ObjLds sm;
-    const int b = (int)blockIdx.x, n0 = P.sched[0];
-    if (b < n0) pmg::step_env_core<1, 24, CYL>(P, actions, P.sched[2 + b], sm.one.L, sm.one.lcs, true);
-    else pmgp::step_group_obj<CYL>(P, actions, b - n0, sm.four);
+    __shared__ pmgp::ObjLds4 sm;
+    pmgp::step_group_obj<CYL>(P, actions, (int)blockIdx.x, sm);
 }
 template <bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvParams P, const float* __restrict__ actions)
@@ -170,7 +162,7 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvP
  * 48-contact store; list 1 = the rest with a 30-contact store (20 KB of LDS instead of 29: 8 workgroups per CU instead
  * of 5).  The two launches run concurrently on two streams; a list-1 env that overflows is queued for the redo pass */
 constexpr int MULTI_SMALL_MAXC = 30;
-template <int NB, int MAXC, int LIST>
+template <int NB, int MAXC, int LIST, bool CYL = false>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmg::ContactLds<NB, MAXC> L;
@@ -178,7 +170,7 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::Env
     const int b = (int)blockIdx.x;
     if (b >= P.sched[LIST]) return;
     const int env = P.sched[2 + LIST * P.n_envs + b];
-    const bool ok = pmg::step_env_core<NB, MAXC, false>(P, actions, env, L, lcs, true);
+    const bool ok = pmg::step_env_core<NB, MAXC, CYL>(P, actions, env, L, lcs, true);
     if (!ok && threadIdx.x == 0) {
         int* redo = P.sched + 2 + 2 * P.n_envs;
         int slot = atomicAdd(redo, 1);
@@ -194,7 +186,7 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_multi(pmg::En
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
                            hipEvent_t ev_fork, hipEvent_t ev_join)
 {
-    if (P.nb > 1 && !P.joint_control && packed) {
+    if (P.nb > 1 && packed) {
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         hipLaunchKernelGGL((pmg_k_step_list<5, 48, 0>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
@@ -206,18 +198,26 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         hipLaunchKernelGGL(pmg_k_redo_multi, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         return hipGetLastError();
     }
-    if (P.nb == 1 && !P.joint_control && packed) {
-        const int groups = P.n_envs; /* n_prone + ceil(n_free / 4) <= N */
+    if (P.nb == 1 && packed) {
+        (void)hipEventRecord(ev_fork, s);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        const int groups = (P.n_envs + 3) / 4;
         if (P.task == PMG_TASK_SLIDE) {
+            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+            (void)hipEventRecord(ev_join, side);
             hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(64), 0, s, P, d_actions);
+            (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         } else {
+            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+            (void)hipEventRecord(ev_join, side);
             hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(64), 0, s, P, d_actions);
+            (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL((pmg_k_redo_obj<false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         }
         return hipGetLastError();
     }
-    if (P.nb == 0 && !P.joint_control && packed) {
+    if (P.nb == 0 && packed) {
         hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs), dim3(64), 0, s, P, d_actions); /* n_prone + ceil(n_free/4) <= N */
         /* mispredictions are rare; surplus workgroups of the redo grid exit on their first instruction */
         hipLaunchKernelGGL(pmg_k_redo, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);

@@ -85,9 +85,11 @@ __device__ __forceinline__ void write_outputs_reach(const EnvParams& P, int env,
     float* ag = pol + P.pdim;
     float* dg = ag + P.gdim;
     float* tail = dg + P.gdim;
+    const int jo = P.joint_control ? 7 : 0;
+    if (jo && l < 7) { obs[l] = q; pol[l] = q; }                /* joint angles first: kuka_single_step_base_env.py:214-216 */
     if (l < 3) {
         float x = l == 0 ? tip[0] : (l == 1 ? tip[1] : tip[2]);
-        obs[l] = x; pol[l] = x; ag[l] = x;
+        obs[jo + l] = x; pol[jo + l] = x; ag[l] = x;
         dg[l] = g[l];
     }
     float dd = 0.f;
@@ -123,15 +125,21 @@ __device__ __forceinline__ void step_group(const EnvParams& P, const float* acti
     int elapsed = (int)hot[29];
     float mtarget = grip, mimp = FINGER_FORCE * PHYSICS_DT;
     float ee[3] = {hot[18], hot[19], hot[20]};
-#pragma unroll
-    for (int a = 0; a < 3; a++) {                      /* kuka.py:209-212 */
-        float t = ee[a] + act[a] * 0.01f;
-        ee[a] = fminf(fmaxf(t, P.ee_lo[a]), P.ee_hi[a]);
-    }
+    float jt = l < 7 ? hot[21 + l] : 0.f;
     PMGP_T0();
-    float qik = ik_solve(c, q, ee);                    /* kuka.py:214 */
-    PMGP_T(7);
-    if (l < 7) { mtarget = qik; mimp = ARM_FORCE * PHYSICS_DT; } /* kuka.py:282-290 */
+    if (P.joint_control) {
+        if (l < 7) { jt = act[l] * 0.05f + jt; mtarget = jt; }   /* kuka.py:205 */
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {                  /* kuka.py:209-212 */
+            float t = ee[a] + act[a] * 0.01f;
+            ee[a] = fminf(fmaxf(t, P.ee_lo[a]), P.ee_hi[a]);
+        }
+        float qik = ik_solve(c, q, ee);                /* kuka.py:214 */
+        PMGP_T(7);
+        if (l < 7) mtarget = qik;
+    }
+    if (l < 7) mimp = ARM_FORCE * PHYSICS_DT;          /* kuka.py:282-290 */
     bool ok = true;
     for (int s = 0; s < SIM_STEPS && ok; s++) {        /* kuka.py:223-225 */
         float tau = -c.jdamp() * qd;                   /* joint damping latched per stepSimulation */
@@ -150,6 +158,7 @@ __device__ __forceinline__ void step_group(const EnvParams& P, const float* acti
     elapsed++;
     if (l < NJ) { hot[l] = q; hot[9 + l] = qd; }
     if (l < 3) hot[18 + l] = l == 0 ? ee[0] : (l == 1 ? ee[1] : ee[2]);
+    if (l < 7) hot[21 + l] = jt;
     if (l == 0) { hot[29] = (float)elapsed; hot[30] = 1.f; }
     write_outputs_reach(P, env, c, q, elapsed);
 }
