@@ -954,6 +954,28 @@ static void closest_on_box(const real* cb, const real (*B)[3], const real* hb, c
         v3axpy(q, t, B[k]);
     }
 }
+/* closest point of the solid cylinder (centre cc, axis a, radius rad, half length hl) to p */
+static void closest_on_cyl(const real* cc, const real* a, real rad, real hl, const real* p, real* q)
+{
+    real w[3], r[3];
+    v3sub(w, p, cc);
+    real wa = v3dot(w, a);
+    real ta = wa < -hl ? -hl : (wa > hl ? hl : wa);
+    for (int x = 0; x < 3; x++) r[x] = w[x] - wa * a[x];
+    real rl = v3norm(r);
+    real sc = rl > rad ? rad / rl : 1;
+    for (int x = 0; x < 3; x++) q[x] = cc[x] + ta * a[x] + sc * r[x];
+}
+/* mutual closest points of the cylinder and the box by alternating projections (disjoint convex sets) */
+static void cyl_box_closest(const real* cc, const real* a, real rad, real hl, const real* cb, const real (*B)[3],
+                            const real* hb, real* qc, real* p0)
+{
+    closest_on_box(cb, B, hb, cc, p0);
+    for (int it = 0; it < 6; it++) {
+        closest_on_cyl(cc, a, rad, hl, p0, qc);
+        closest_on_box(cb, B, hb, qc, p0);
+    }
+}
 static int reduce4(const real (*pts)[3], const real* sep, int m, int* sel)
 {
     if (m <= 4) { for (int c = 0; c < m; c++) sel[c] = c; return m; }
@@ -1006,15 +1028,10 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             if (len < (real)1e-6) continue;
             for (int x = 0; x < 3; x++) L[x] /= len;
         } else {
-            type = 3;
-            real p0[3], s0[3], w[3];
-            closest_on_box(cb, B, hb, cc, p0);
-            v3sub(w, p0, cc);
-            real t = v3dot(w, a);
-            t = t < -hl ? -hl : (t > hl ? hl : t);
-            v3cpy(s0, cc); v3axpy(s0, t, a);
-            closest_on_box(cb, B, hb, s0, p0);
-            v3sub(L, s0, p0);
+            type = 3; /* the direction between the mutual closest points (vertex / rim configurations) */
+            real p0[3], qc[3];
+            cyl_box_closest(cc, a, rad, hl, cb, (const real (*)[3])B, hb, qc, p0);
+            v3sub(L, qc, p0);
             real len = v3norm(L);
             if (len < (real)1e-9) continue;
             for (int x = 0; x < 3; x++) L[x] /= len;
@@ -1044,6 +1061,20 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             real sg = can > 0 ? (real)-1 : (real)1;    /* the cap that faces the box */
             real pc[3];
             v3cpy(pc, cc); v3axpy(pc, sg * hl, a);
+            {   /* a tilted cap touches with ONE rim point, the lowest along n: it leads the candidates (the four fixed
+                 * samples below would only find the contact several mm too late) */
+                real md[3];
+                for (int x = 0; x < 3; x++) md[x] = n[x] - can * a[x];
+                real ml = v3norm(md);
+                if (ml > (real)1e-3) {
+                    real p[3], w[3];
+                    v3cpy(p, pc); v3axpy(p, -rad / ml, md);
+                    v3sub(w, p, cb);
+                    if (RFABS(v3dot(w, B[j1])) <= hb[j1] && RFABS(v3dot(w, B[j2])) <= hb[j2]) {
+                        v3cpy(pts[m], p); v3sub(w, p, fp); sep[m] = v3dot(w, n); m++;
+                    }
+                }
+            }
             for (int c = 0; c < 4; c++) {              /* rim points inside the face rectangle */
                 real p[3], w[3];
                 v3cpy(p, pc);
@@ -1131,17 +1162,24 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             v3cpy(pts[m], q); v3axpy(pts[m], -wa, n); sep[m] = -wa; m++;
         }
     } else {
-        /* one point: closest points of the axis segment and the box, pushed to the lateral surface */
-        real p0[3], s0[3], w[3];
-        closest_on_box(cb, B, hb, cc, p0);
-        for (int it = 0; it < 4; it++) {
-            v3sub(w, p0, cc);
-            real t = v3dot(w, a);
-            t = t < -hl ? -hl : (t > hl ? hl : t);
-            v3cpy(s0, cc); v3axpy(s0, t, a);
-            closest_on_box(cb, B, hb, s0, p0);
+        /* one point.  Closest-feature direction: the cylinder's point of the mutual closest pair.  Axis x edge direction
+         * (n perpendicular to the axis, a lateral contact): the generator facing the box, at the axial position next to
+         * the box found by alternating closest points of the axis segment and the box */
+        if (btype == 3) {
+            real p0[3];
+            cyl_box_closest(cc, a, rad, hl, cb, (const real (*)[3])B, hb, pts[0], p0);
+        } else {
+            real p0[3], s0[3], w[3];
+            closest_on_box(cb, B, hb, cc, p0);
+            for (int it = 0; it < 4; it++) {
+                v3sub(w, p0, cc);
+                real t = v3dot(w, a);
+                t = t < -hl ? -hl : (t > hl ? hl : t);
+                v3cpy(s0, cc); v3axpy(s0, t, a);
+                closest_on_box(cb, B, hb, s0, p0);
+            }
+            v3cpy(pts[0], s0); v3axpy(pts[0], -rad, n);
         }
-        v3cpy(pts[0], s0); v3axpy(pts[0], -rad, n);
         sep[0] = best;
         m = 1;
     }

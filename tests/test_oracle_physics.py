@@ -181,3 +181,63 @@ def test_stacked_blocks_stay_stacked_and_energy_does_not_grow(built):
     assert np.abs(s[64:67] - [-0.45, 0.12, 0.175]).max() < 5e-4
     assert np.abs(s[77:80] - [-0.45, 0.12, 0.205]).max() < 1e-3
     assert max(ke) < 1e-3                               # no energy injected at rest (un-warm-started PGS jitter <~ 1 cm/s)
+
+
+def _rand_rot(rs):
+    q = rs.normal(size=4)
+    q /= np.linalg.norm(q)
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize('shape', ['box', 'cyl'])
+def test_narrowphase_invariants_at_first_touch(built, shape):
+    """Random orientations, the two bodies brought together along a random direction in 0.5 mm steps until the first
+    contacts appear (the regime the simulation lives in: separations within the 2 mm margin, penetrations < 1 mm).
+    Every contact set must have unit normals, distance = separation of the witness points along the normal, witness
+    points on their shapes (to the step size), at most four points, and be equivariant under a common rigid motion."""
+    rs = np.random.RandomState(11)
+    hb = np.array([0.015, 0.015, 0.015])
+    ha = np.array([0.0125, 0.005, 0.04])
+    if shape == 'box':
+        f = lambda ca_, Ra_, cb_, Rb_: O.box_box(ca_, Ra_.ravel(), ha, cb_, Rb_.ravel(), hb)
+    else:
+        f = lambda ca_, Ra_, cb_, Rb_: O.cyl_box(ca_, Ra_.ravel(), 0.03, 0.01, cb_, Rb_.ravel(), hb)
+    for trial in range(60):
+        Ra, Rb = _rand_rot(rs), _rand_rot(rs)
+        if trial % 3 == 0:                       # a third of the trials face to face (axis-aligned, the resting case)
+            Ra, Rb = np.eye(3), np.eye(3)
+        cb = rs.uniform(-0.1, 0.1, 3)
+        u = rs.normal(size=3)
+        if trial % 3 == 0:
+            u = np.eye(3)[rs.randint(3)] * rs.choice([-1, 1]) + rs.normal(size=3) * 1e-3
+        u /= np.linalg.norm(u)
+        c, ca = [], None
+        for step in range(200):
+            ca = cb + u * (0.09 - 0.0005 * step)
+            c = f(ca, Ra, cb, Rb)
+            if len(c):
+                break
+        assert 1 <= len(c) <= 4
+        n = c[:, 6:9]
+        assert np.allclose(np.linalg.norm(n, axis=1), 1, atol=1e-9)
+        assert np.allclose(np.einsum('ij,ij->i', c[:, 0:3] - c[:, 3:6], n), c[:, 9], atol=1e-9)   # dist along n (B -> A)
+        assert (c[:, 9] <= 0.002 + 1e-12).all() and c[:, 9].min() > -0.0015
+        assert (n @ u > 0).all()                                                                   # pushes A away from B
+        # contact margin + step size; cyl_box's box witness is the cylinder's point dropped along the (iteratively
+        # estimated) closest-feature direction, a few mm off a box vertex at worst: it only enters B's lever arm
+        slack = 2.5e-3 if shape == 'box' else 5e-3
+        lb = (c[:, 3:6] - cb) @ Rb
+        assert (np.abs(lb) <= hb + slack).all()
+        la = (c[:, 0:3] - ca) @ Ra
+        if shape == 'box':
+            assert (np.abs(la) <= ha + slack).all()
+        else:
+            assert (np.hypot(la[:, 0], la[:, 1]) <= 0.03 + slack).all() and (np.abs(la[:, 2]) <= 0.01 + slack).all()
+        Q, t = _rand_rot(rs), rs.uniform(-1, 1, 3)
+        c2 = f(Q @ ca + t, Q @ Ra, Q @ cb + t, Q @ Rb)
+        assert len(c2) == len(c)
+        assert np.allclose(np.sort(c2[:, 9]), np.sort(c[:, 9]), atol=1e-7)
+        assert np.allclose(c2[:, 6:9].mean(0), Q @ n.mean(0), atol=1e-6)
