@@ -1015,6 +1015,7 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
     v3sub(d, cc, cb);
     real best = (real)-1e30, bn[3] = {0, 0, 0};
     int btype = -1, bk = 0;
+    real q3[3] = {0, 0, 0}, L3[3] = {0, 0, 0}, len3 = -1;   /* mutual closest pair (cylinder point, direction, distance) */
     /* type 0: box faces, 1: cylinder axis, 2: axis x edge, 3: closest feature */
     for (int pass = 0; pass < 8; pass++) {
         real L[3];
@@ -1035,6 +1036,7 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             real len = v3norm(L);
             if (len < (real)1e-9) continue;
             for (int x = 0; x < 3; x++) L[x] /= len;
+            v3cpy(q3, qc); v3cpy(L3, L); len3 = len;
         }
         real t = v3dot(d, L), ca = v3dot(a, L);
         real rc = hl * RFABS(ca) + rad * RSQRT(1 - ca * ca > 0 ? 1 - ca * ca : 0);
@@ -1062,17 +1064,23 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             real pc[3];
             v3cpy(pc, cc); v3axpy(pc, sg * hl, a);
             {   /* a tilted cap touches with ONE rim point, the lowest along n: it leads the candidates (the four fixed
-                 * samples below would only find the contact several mm too late) */
+                 * samples below would only find the contact several mm too late).  When the cap hangs over an edge of
+                 * the face the point is moved inside the face rectangle along the face, as the side case does; the
+                 * depth stays that of the rim point */
                 real md[3];
                 for (int x = 0; x < 3; x++) md[x] = n[x] - can * a[x];
                 real ml = v3norm(md);
                 if (ml > (real)1e-3) {
                     real p[3], w[3];
                     v3cpy(p, pc); v3axpy(p, -rad / ml, md);
+                    v3sub(w, p, fp);
+                    real sd = v3dot(w, n);
                     v3sub(w, p, cb);
-                    if (RFABS(v3dot(w, B[j1])) <= hb[j1] && RFABS(v3dot(w, B[j2])) <= hb[j2]) {
-                        v3cpy(pts[m], p); v3sub(w, p, fp); sep[m] = v3dot(w, n); m++;
-                    }
+                    real c1 = v3dot(w, B[j1]), c2 = v3dot(w, B[j2]);
+                    real k1 = c1 < -hb[j1] ? -hb[j1] : (c1 > hb[j1] ? hb[j1] : c1);
+                    real k2 = c2 < -hb[j2] ? -hb[j2] : (c2 > hb[j2] ? hb[j2] : c2);
+                    v3axpy(p, k1 - c1, B[j1]); v3axpy(p, k2 - c2, B[j2]);
+                    v3cpy(pts[m], p); sep[m] = sd; m++;
                 }
             }
             for (int c = 0; c < 4; c++) {              /* rim points inside the face rectangle */
@@ -1188,7 +1196,31 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
         for (int c = 0; c < m; c++)
             if (sep[c] <= margin) { if (k2 != c) { v3cpy(pts[k2], pts[c]); sep[k2] = sep[c]; } k2++; }
         m = k2;
-        if (m == 0) return 0;
+        if (m == 0) {
+            /* the face / axis case found overlap along its axis but no feature point within the margin: an edge or vertex
+             * passing beside the rim.  The mutual closest pair IS the contact then; the alternating projections are
+             * continued until they settle (an edge nearly parallel to the cap converges slowly, the six iterations of
+             * the axis pass are not enough there) */
+            if (len3 < 0) return 0;
+            real qc[3], p0[3], pn[3], w[3];
+            v3cpy(p0, q3); v3axpy(p0, -len3, L3);
+            for (int it = 0; it < 48; it++) {
+                closest_on_cyl(cc, a, rad, hl, p0, qc);
+                closest_on_box(cb, (const real (*)[3])B, hb, qc, pn);
+                v3sub(w, pn, p0);
+                v3cpy(p0, pn);
+                if (v3dot(w, w) < (real)1e-12) break;
+            }
+            v3sub(w, qc, p0);
+            real len = v3norm(w);
+            if (len > margin) return 0;
+            if (len > (real)1e-6) v3set(out[0].n, w[0] / len, w[1] / len, w[2] / len);
+            else { v3cpy(out[0].n, bn); len = 0; }          /* already touching: the winning axis, no depth */
+            v3cpy(out[0].pa, qc);
+            v3cpy(out[0].pb, p0);
+            out[0].dist = len;
+            return 1;
+        }
     }
     int sel[4];
     int ns = reduce4((const real (*)[3])pts, sep, m, sel);

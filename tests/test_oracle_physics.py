@@ -228,7 +228,9 @@ def test_narrowphase_invariants_at_first_touch(built, shape):
         assert (n @ u > 0).all()                                                                   # pushes A away from B
         # contact margin + step size; cyl_box's box witness is the cylinder's point dropped along the (iteratively
         # estimated) closest-feature direction, a few mm off a box vertex at worst: it only enters B's lever arm
-        slack = 2.5e-3 if shape == 'box' else 5e-3
+        # box: the edge-edge case takes closest points of the two edge LINES (ODE / Bullet dLineClosestApproach), which may
+        # overshoot an edge's end; cylinder: a rim point hanging over a face edge is moved along the face into the rectangle
+        slack = 8e-3
         lb = (c[:, 3:6] - cb) @ Rb
         assert (np.abs(lb) <= hb + slack).all()
         la = (c[:, 0:3] - ca) @ Ra
