@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 # algorithmic bytes per env-step (state r+w, action, outputs)
-ALGO_BYTES = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242}
+ALGO_BYTES = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242,
+              # chest tasks with 4 blocks: state (24 + 4*13 + 3 door floats, order, counter + RNG cursor) r+w 704, action, outputs 618
+              'chest_push': 1334, 'chest_pick_and_place': 1338}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 

@@ -30,14 +30,17 @@
 extern "C" {
 #endif
 
-/* tasks: P/__init__.py:14-40 ('reach','push','pick_and_place','slide','block_stack','block_rearrange') */
+/* tasks: P/__init__.py:14-44 ('reach','push','pick_and_place','slide','block_stack','block_rearrange','chest_push',
+ * 'chest_pick_and_place') */
 enum {
     PMG_TASK_REACH = 0,
     PMG_TASK_PUSH = 1,
     PMG_TASK_PICK_AND_PLACE = 2,
     PMG_TASK_SLIDE = 3,
     PMG_TASK_BLOCK_STACK = 4,
-    PMG_TASK_BLOCK_REARRANGE = 5
+    PMG_TASK_BLOCK_REARRANGE = 5,
+    PMG_TASK_CHEST_PUSH = 6,            /* KukaChestPushEnv: front sliding door (kuka_multi_step_envs.py:385-403) */
+    PMG_TASK_CHEST_PICK_AND_PLACE = 7   /* KukaChestPickAndPlaceEnv: up sliding lid (:230-254) */
 };
 
 enum {

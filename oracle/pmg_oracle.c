@@ -1304,6 +1304,12 @@ struct pmgo_env {
     int multi;                   /* multi-block observation layout (block_stack / block_rearrange) */
     int curriculum_update;       /* activate_curriculum_update() */
     double goals_per_curriculum; /* num_goals_to_generate // num_curriculum */
+    int chest;                   /* -1 none, 0 front sliding door (chest_push), 1 up sliding lid (chest_pick_and_place) */
+    int nwall;
+    real wall_c[5][3], wall_h[5][3];   /* static chest walls, world frame (never rotated: chest.py:33) */
+    real door_c0[3], door_h[3], door_axis[3], door_upper, door_mass, door_open;
+    real handle_c[3], handle_R[9], handle_rad, handle_hl;   /* handle cylinder, relative to the door centre */
+    real keypoint[3][3];
     int obj_cyl;                 /* the single free object is the slide puck (cylinder) */
     real obj_inertia[3], obj_half[3], obj_mu; /* principal inertia, half extents (cyl: r, r, h/2), friction */
     World* w;
@@ -1315,6 +1321,10 @@ static char g_create_err[256];
 /* body ids in contacts: 0..NBMAX-1 blocks, 100+L robot Bullet link L, -1 static */
 #define BODY_STATIC (-1)
 #define BODY_ROBOT(L) (100 + (L))
+#define BODY_DOOR 50        /* the chest door: one prismatic DoF (door + handle), state in World.goal[0..2] */
+#define DOOR_Q(w) ((w)->goal[0])
+#define DOOR_QD(w) ((w)->goal[1])
+#define DOOR_MOTOR(w) ((w)->goal[2])   /* 1 once _get_obs found the door open and latched the position motor */
 
 typedef struct {
     int a, b;
@@ -1328,6 +1338,7 @@ typedef struct {
     int blk[2];           /* block ids (-1 none) */
     real Jl[2][3], Ja[2][3];
     real dl[2][3], da[2][3];
+    real Jd, dd;          /* chest door: Jacobian on the joint velocity and its response Jd / m */
     real diag_inv, rhs, lo, hi, applied, mu;
     int fric_of;          /* index of the normal row for friction rows */
 } Row;
@@ -1356,6 +1367,14 @@ static void row_setup(const pmgo_env* e, const World* w, const Kin* k, const Aba
         real sg = s == 0 ? (real)1 : (real)-1;
         int id = bodies[s];
         if (id == BODY_STATIC) continue;
+        if (id == BODY_DOOR) { /* a prismatic link on a fixed base: only the axis component of the direction acts */
+            real jd = sg * v3dot(n, e->door_axis);
+            r->Jd += jd;
+            r->dd = r->Jd / e->door_mass;
+            denom += jd * jd / e->door_mass;
+            rel += jd * DOOR_QD(w);
+            continue;
+        }
         if (id >= 100) {
             real J[NJ], nn[3] = {sg * n[0], sg * n[1], sg * n[2]};
             point_jacobian(k, id - 100, pts[s], nn, J);
@@ -1466,6 +1485,58 @@ static int collide(const pmgo_env* e, const World* w, const Kin* k, Contact* out
                              e->obj_half, CONTACT_MARGIN, cp);
             EMIT(BODY_ROBOT(PMG_BL_GBASE), b, GBASE_FRICTION * e->obj_mu)
         }
+    /* chest (kuka_multi_step_base_env.py:97-110, chest.py): blocks, fingers and the gripper base against the static walls
+     * and the door box; fingers against the door handle.  Not generated (build choice): door x walls / table
+     * (the door cannot move along those normals), handle x blocks, handle x gripper base */
+    if (e->chest >= 0) {
+        real bc[5][3];
+        const real* bh[5];
+        int nbox = e->nwall + 1;
+        for (int x = 0; x < e->nwall; x++) { v3cpy(bc[x], e->wall_c[x]); bh[x] = e->wall_h[x]; }
+        v3cpy(bc[e->nwall], e->door_c0);
+        v3axpy(bc[e->nwall], DOOR_Q(w), e->door_axis);
+        bh[e->nwall] = e->door_h;
+#define BOX_ID(x) ((x) == e->nwall ? BODY_DOOR : BODY_STATIC)
+#define NEAR_BOX(P, RAD, x) (RFABS((P)[0] - bc[x][0]) <= bh[x][0] + (RAD) && RFABS((P)[1] - bc[x][1]) <= bh[x][1] + (RAD) && \
+                             RFABS((P)[2] - bc[x][2]) <= bh[x][2] + (RAD))
+        for (int b = 0; b < e->nb; b++)
+            for (int x = 0; x < nbox; x++) {
+                if (!NEAR_BOX(w->blk[b].pos, (real)0.026 + CONTACT_MARGIN, x)) continue;
+                int n_ = box_box(w->blk[b].pos, Rb[b], e->obj_half, bc[x], I3, bh[x], CONTACT_MARGIN, cp);
+                EMIT(b, BOX_ID(x), e->obj_mu * (real)PMG_CHEST_WALL_FRICTION)
+            }
+        for (int f = 0; f < 2; f++) {
+            real fc[3], fR[9];
+            robot_box_pose(k, FL[f], fc, fR);
+            for (int x = 0; x < nbox; x++) {
+                if (!NEAR_BOX(fc, (real)0.0431 + CONTACT_MARGIN, x)) continue;
+                int n_ = box_box(fc, fR, fh, bc[x], I3, bh[x], CONTACT_MARGIN, cp);
+                EMIT(BODY_ROBOT(FL[f]), BOX_ID(x), (real)PMG_FINGER_FRICTION * (real)PMG_CHEST_WALL_FRICTION)
+            }
+            real hc[3], dd[3];
+            v3add(hc, bc[e->nwall], e->handle_c);
+            v3sub(dd, fc, hc);
+            real lim = (real)0.0431 + e->handle_hl + e->handle_rad + CONTACT_MARGIN;
+            if (v3dot(dd, dd) <= lim * lim) {
+                int n_ = cyl_box(hc, e->handle_R, e->handle_rad, e->handle_hl, fc, fR, fh, CONTACT_MARGIN, cp);
+                for (int c2 = 0; c2 < n_; c2++) { /* cyl_box reports the cylinder as A: the finger is A here */
+                    real t[3];
+                    v3cpy(t, cp[c2].pa); v3cpy(cp[c2].pa, cp[c2].pb); v3cpy(cp[c2].pb, t);
+                    v3set(cp[c2].n, -cp[c2].n[0], -cp[c2].n[1], -cp[c2].n[2]);
+                }
+                EMIT(BODY_ROBOT(FL[f]), BODY_DOOR, (real)PMG_FINGER_FRICTION * (real)PMG_CHEST_HANDLE_FRICTION)
+            }
+        }
+        for (int x = 0; x < nbox; x++) {
+            const real* gc = k->p[PMG_BL_GBASE];
+            if (!NEAR_BOX(gc, (real)0.0539 + CONTACT_MARGIN, x)) continue;
+            int n_ = cyl_box(gc, k->R[PMG_BL_GBASE], (real)PMG_GBASE_RADIUS, (real)PMG_GBASE_HALFLEN, bc[x], I3, bh[x],
+                             CONTACT_MARGIN, cp);
+            EMIT(BODY_ROBOT(PMG_BL_GBASE), BOX_ID(x), GBASE_FRICTION * (real)PMG_CHEST_WALL_FRICTION)
+        }
+#undef BOX_ID
+#undef NEAR_BOX
+    }
 #undef EMIT
     return nc;
 }
@@ -1486,9 +1557,9 @@ static void plane_space(const real* n, real* p, real* q)
     }
 }
 
-static real row_solve(Row* r, real* dqd, real (*dbl)[3], real (*dba)[3])
+static real row_solve(Row* r, real* dqd, real (*dbl)[3], real (*dba)[3], real* ddoor)
 {
-    real dv = 0;
+    real dv = r->Jd * *ddoor;
     if (r->has_robot)
         for (int d = 0; d < NJ; d++) dv += r->Jr[d] * dqd[d];
     for (int s = 0; s < 2; s++)
@@ -1500,6 +1571,7 @@ static real row_solve(Row* r, real* dqd, real (*dbl)[3], real (*dba)[3])
     else r->applied = sum;
     if (r->has_robot)
         for (int d = 0; d < NJ; d++) dqd[d] += r->dvr[d] * delta;
+    *ddoor += r->dd * delta;
     for (int s = 0; s < 2; s++)
         if (r->blk[s] >= 0) { v3axpy(dbl[r->blk[s]], delta, r->dl[s]); v3axpy(dba[r->blk[s]], delta, r->da[s]); }
     return r->diag_inv != 0 ? delta / r->diag_inv : 0;
@@ -1578,6 +1650,38 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
             }
         }
     }
+    /* chest door: joint limits ([BULLET-PRIOR] btMultiBodyJointLimitConstraint, as above) and, once latched by
+     * _get_obs, the position motor of chest.py:59-68 (force 500, gains 0.03 / 1).  Solved after the robot's
+     * non-contact rows, in this order, every iteration */
+    Row drow[3];
+    int nd = 0;
+    if (e->chest >= 0) {
+        real dm_inv = 1 / e->door_mass;
+        if (DOOR_MOTOR(w) != 0) {
+            Row* r = &drow[nd++];
+            memset(r, 0, sizeof(*r));
+            r->blk[0] = r->blk[1] = -1;
+            r->Jd = 1; r->dd = dm_inv;
+            r->diag_inv = e->door_mass;
+            real target_v = ARM_KP * (e->door_open - DOOR_Q(w)) / dt + DOOR_QD(w) + ARM_KD * (0 - DOOR_QD(w));
+            r->rhs = (target_v - DOOR_QD(w)) * r->diag_inv;
+            r->lo = -(real)500.0 * PHYSICS_DT;
+            r->hi = (real)500.0 * PHYSICS_DT;
+        }
+        for (int side = 0; side < 2; side++) {
+            real pen = side == 0 ? DOOR_Q(w) : e->door_upper - DOOR_Q(w);
+            if (pen > 0) continue;
+            Row* r = &drow[nd++];
+            memset(r, 0, sizeof(*r));
+            r->blk[0] = r->blk[1] = -1;
+            r->Jd = side == 0 ? (real)1 : (real)-1;
+            r->dd = r->Jd * dm_inv;
+            r->diag_inv = e->door_mass;
+            r->rhs = (-pen * JOINT_ERP / dt - r->Jd * DOOR_QD(w)) * r->diag_inv;
+            r->lo = 0;
+            r->hi = LIMIT_MAX_IMPULSE;
+        }
+    }
     Row nrm[MAX_CONTACTS], fri[2 * MAX_CONTACTS];
     for (int c = 0; c < nc; c++) {
         /* [BULLET-PRIOR] btMultiBodyConstraintSolver::setupMultiBodyContactConstraint */
@@ -1605,7 +1709,7 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
         }
     }
     /* 4. projected Gauss-Seidel, [BULLET-PRIOR] btMultiBodyConstraintSolver::solveSingleIteration */
-    real dqd[NJ], dbl[NBMAX][3], dba[NBMAX][3];
+    real dqd[NJ], dbl[NBMAX][3], dba[NBMAX][3], ddoor = 0;
     memset(dqd, 0, sizeof(dqd));
     memset(dbl, 0, sizeof(dbl));
     memset(dba, 0, sizeof(dba));
@@ -1613,11 +1717,15 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
         real resid = 0;
         for (int j = 0; j < nn; j++) {
             int idx = (it & 1) ? j : nn - 1 - j;
-            real dv = row_solve(&nonc[idx], dqd, dbl, dba);
+            real dv = row_solve(&nonc[idx], dqd, dbl, dba, &ddoor);
+            resid = dv * dv > resid ? dv * dv : resid;
+        }
+        for (int j = 0; j < nd; j++) {
+            real dv = row_solve(&drow[j], dqd, dbl, dba, &ddoor);
             resid = dv * dv > resid ? dv * dv : resid;
         }
         for (int c = 0; c < nc; c++) {
-            real dv = row_solve(&nrm[c], dqd, dbl, dba);
+            real dv = row_solve(&nrm[c], dqd, dbl, dba, &ddoor);
             resid = dv * dv > resid ? dv * dv : resid;
         }
         for (int c = 0; c < 2 * nc; c++) {
@@ -1626,7 +1734,7 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
             if (tot > 0) {
                 fr->lo = -fr->mu * tot;
                 fr->hi = fr->mu * tot;
-                real dv = row_solve(fr, dqd, dbl, dba);
+                real dv = row_solve(fr, dqd, dbl, dba, &ddoor);
                 resid = dv * dv > resid ? dv * dv : resid;
             }
         }
@@ -1635,6 +1743,7 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
     for (int d = 0; d < NJ; d++) w->qd[d] += dqd[d];
     /* 5. integrate positions */
     for (int d = 0; d < NJ; d++) w->q[d] += dt * w->qd[d];
+    if (e->chest >= 0) { DOOR_QD(w) += ddoor; DOOR_Q(w) += dt * DOOR_QD(w); }
     for (int b = 0; b < e->nb; b++) {
         Block* bl = &w->blk[b];
         for (int a = 0; a < 3; a++) { bl->vel[a] += dbl[b][a]; bl->omg[a] += dba[b][a]; }
@@ -1670,13 +1779,14 @@ static void env_constants(pmgo_env* e)
 {
     const pmg_config* c = &e->cfg;
     int t = c->task;
-    e->grasping = (t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
+    e->chest = t == PMG_TASK_CHEST_PUSH ? 0 : (t == PMG_TASK_CHEST_PICK_AND_PLACE ? 1 : -1);
+    e->grasping = (t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_CHEST_PICK_AND_PLACE);
     e->has_obj = (t != PMG_TASK_REACH);
-    e->in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
-    e->start_on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE || t == PMG_TASK_BLOCK_REARRANGE); /* kuka_multi_step_envs.py:169 */
-    e->multi = (t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_BLOCK_REARRANGE);
+    e->in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_CHEST_PICK_AND_PLACE);
+    e->start_on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE || t == PMG_TASK_BLOCK_REARRANGE || t == PMG_TASK_CHEST_PUSH); /* kuka_multi_step_envs.py:169,250,399 */
+    e->multi = (t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_BLOCK_REARRANGE || e->chest >= 0);
     e->nb = t == PMG_TASK_REACH ? 0 : (e->multi ? c->num_block : 1);
-    real obj_range = t == PMG_TASK_SLIDE ? (real)0.1 : (real)0.15, tgt_range = t == PMG_TASK_SLIDE ? (real)0.2 : (real)0.15;
+    real obj_range = (t == PMG_TASK_SLIDE || e->chest >= 0) ? (real)0.1 : (real)0.15, /* kuka_multi_step_envs.py:251,400 */ tgt_range = t == PMG_TASK_SLIDE ? (real)0.2 : (real)0.15;
     /* kuka.py:35-51 */
     v3set(e->tip_init, (real)-0.52, 0, (real)0.25);
     if (e->start_on_table) e->tip_init[2] = (real)0.175 + (real)0.001;
@@ -1689,6 +1799,28 @@ static void env_constants(pmgo_env* e)
     e->obj_lo[0] += (real)0.03; e->obj_hi[0] -= (real)0.03;
     e->tgt_lo[0] += (real)0.03; e->tgt_hi[0] -= (real)0.03;
     e->tgt_lo[2] = e->ee_lo[2];
+    if (e->chest >= 0) { /* kuka_multi_step_base_env.py:97-110 + the chest URDFs (include/pmg_model.h) */
+        static const double CB[3] = PMG_CHEST_BASE, WC[2][4][3] = PMG_CHEST_WALL_C, WH[2][4][3] = PMG_CHEST_WALL_HALF;
+        static const double DC[2][3] = PMG_CHEST_DOOR_C, DH[2][3] = PMG_CHEST_DOOR_HALF, DA[2][3] = PMG_CHEST_DOOR_AXIS;
+        static const double DU[2] = PMG_CHEST_DOOR_UPPER, DM[2] = PMG_CHEST_DOOR_MASS, HC[2][3] = PMG_CHEST_HANDLE_C;
+        static const double HR[2][3][3] = PMG_CHEST_HANDLE_R, HRAD[2] = PMG_CHEST_HANDLE_RADIUS, HHL[2] = PMG_CHEST_HANDLE_HALFLEN;
+        static const double KP[2][3][3] = PMG_CHEST_KEYPOINTS;
+        static const int NW[2] = PMG_CHEST_NWALL;
+        int k = e->chest;
+        e->obj_lo[0] += (real)0.05; e->obj_hi[0] += (real)0.05;
+        e->obj_lo[1] -= (real)0.05; e->obj_hi[1] += (real)0.05;
+        e->nwall = NW[k];
+        for (int x = 0; x < e->nwall; x++)
+            for (int a = 0; a < 3; a++) { e->wall_c[x][a] = (real)(CB[a] + WC[k][x][a]); e->wall_h[x][a] = (real)WH[k][x][a]; }
+        for (int a = 0; a < 3; a++) {
+            e->door_c0[a] = (real)(CB[a] + DC[k][a]); e->door_h[a] = (real)DH[k][a]; e->door_axis[a] = (real)DA[k][a];
+            e->handle_c[a] = (real)HC[k][a];
+            for (int b = 0; b < 3; b++) { e->handle_R[3 * a + b] = (real)HR[k][a][b]; e->keypoint[a][b] = (real)KP[k][a][b]; }
+        }
+        e->door_upper = (real)DU[k]; e->door_mass = (real)DM[k];
+        e->handle_rad = (real)HRAD[k]; e->handle_hl = (real)HHL[k];
+        e->door_open = e->grasping ? (real)0.1 : (real)0.12;   /* :106-109 */
+    }
     v3set(e->table_c, (real)-0.52, 0, (real)0.08); /* kuka_single_step_base_env.py:49 */
     for (int a = 0; a < 3; a++) e->table_h[a] = (real)TABLE_HALF[a];
     e->table_mu = (real)PMG_TABLE_FRICTION;
@@ -1835,6 +1967,13 @@ static void curriculum_new_target(const pmgo_env* e, World* w)
     }
 }
 
+/* num_steps of the chest tasks: kuka_multi_step_envs.py:238-242, 388-392 */
+static int chest_num_steps(const pmgo_env* e)
+{
+    if (!e->cfg.grip_informed_goal) return e->nb + 1;
+    return e->nb * (e->grasping ? 3 : 2) + 1;
+}
+
 /* multi-block reset: kuka_multi_step_base_env.py:221-250 + kuka_multi_step_envs.py:34-87 (stack),
  * :174-197 (rearrange) */
 static void task_reset_multi(const pmgo_env* e, World* w)
@@ -1856,6 +1995,13 @@ static void task_reset_multi(const pmgo_env* e, World* w)
     /* sub_goal_ind = -1 after reset (kuka_multi_step_base_env.py:248-249): the last sub-goal */
     w->level = (e->cfg.grip_informed_goal && e->cfg.task_decomposition) ? 2 * e->nb - 1 : e->nb - 1;
     w->moved = (1 << e->nb) - 1;
+    if (e->chest >= 0) {
+        /* chest_robot.robot_specific_reset (:242-243, chest.py:40-45): door closed, at rest, motor off.  No random
+         * target: the goal is the chest (kuka_multi_step_envs.py:256-283, 405-431).  sub_goal_ind = -1 = the last step */
+        for (int g = 0; g < 16; g++) w->goal[g] = 0;
+        w->level = chest_num_steps(e) - 1;
+        return;
+    }
     if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
         if (e->cfg.random_order)
             for (int i = e->nb - 1; i >= 1; i--) {
@@ -1891,10 +2037,12 @@ static void task_reset_multi(const pmgo_env* e, World* w)
 
 /* the desired goal as _get_obs re-derives it from the current block poses every observation
  * (kuka_multi_step_base_env.py:309-312 -> _generate_goal(new_target=False) / set_sub_goal) */
+static void chest_goal(const pmgo_env* e, const World* w, double* dg);
 static void effective_goal(const pmgo_env* e, const World* w, double* dg)
 {
     int G = e->dims.goal_dim;
     if (!e->multi) { for (int g = 0; g < G; g++) dg[g] = w->goal[g]; return; }
+    if (e->chest >= 0) { chest_goal(e, w, dg); return; }
     if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
         /* plain / curriculum: the first level+1 blocks of the order sit at their targets.  grip-informed sub-goals
          * come in (pick, place) pairs per block j (kuka_multi_step_envs.py:91-111): pick keeps blocks i < j, place
@@ -1918,6 +2066,53 @@ static void effective_goal(const pmgo_env* e, const World* w, double* dg)
             for (int a = 0; a < 3; a++) dg[3 * b + a] = mv ? w->goal[3 * k + a] : w->blk[b].pos[a];
             k += mv;
         }
+    }
+}
+
+/* chest tasks: _generate_goal / _generate_subgoals of kuka_multi_step_envs.py:256-342 (pick and place), 405-475 (push).
+ * Element 0 is the door joint's open state; blocks in the chest sit at its floor centre, the others where they are now.
+ * Sub-goal 0 (open the door) of the reference also appends the tip position (and finger width) WITHOUT
+ * grip_informed_goal, which makes its length differ from achieved_goal's (the reference then fails its own assert,
+ * kuka_multi_step_base_env.py:314): here the vector is cut to goal_dim. */
+static void chest_goal(const pmgo_env* e, const World* w, double* dg)
+{
+    const double centre[3] = {-0.7 + 0.05, 0.0, 0.175}, top[3] = {-0.7 + 0.05, 0.0, 0.3};
+    int nb = e->nb, pnp = e->grasping, grip = e->cfg.grip_informed_goal;
+    int in_chest = (1 << nb) - 1, lifted = -1;        /* bit b: block b's goal is the chest; lifted: block held above it */
+    int tip_goal = 0;                                 /* gripper goal = the current tip pose */
+    double gx[3], gw = 0.06;
+    for (int a = 0; a < 3; a++) gx[a] = pnp ? top[a] : centre[a] + (a == 0 ? 0.03 : 0.0);
+    if (e->cfg.task_decomposition) {
+        int ind = w->level;
+        if (ind == 0) { in_chest = 0; tip_goal = 1; }
+        else if (!grip) in_chest = (1 << ind) - 1;     /* blocks i <= ind-1 */
+        else if (!pnp) {
+            int j = (ind - 1) / 2, ph = (ind - 1) % 2;
+            in_chest = (1 << (j + ph)) - 1;
+            if (ph == 0) for (int a = 0; a < 3; a++) gx[a] = w->blk[j].pos[a] + (a == 0 ? (real)0.03 : 0);
+        } else {
+            int j = (ind - 1) / 3, ph = (ind - 1) % 3;
+            in_chest = (1 << (j + (ph == 2))) - 1;
+            if (ph == 0) for (int a = 0; a < 3; a++) gx[a] = w->blk[j].pos[a];
+            if (ph == 1) lifted = j;
+            gw = ph == 2 ? 0.06 : 0.03;
+        }
+    }
+    dg[0] = e->door_open;
+    for (int b = 0; b < nb; b++)
+        for (int a = 0; a < 3; a++)
+            dg[1 + 3 * b + a] = b == lifted ? top[a] : (((in_chest >> b) & 1) ? centre[a] : (double)w->blk[b].pos[a]);
+    if (grip) {
+        if (tip_goal) {
+            Kin k;
+            kinematics(w->q, &k);
+            real d[3];
+            v3sub(d, k.p[PMG_BL_TAB1], k.p[PMG_BL_TAB2]);
+            for (int a = 0; a < 3; a++) gx[a] = k.p[PMG_BL_TIP][a];
+            gw = v3norm(d);
+        }
+        for (int a = 0; a < 3; a++) dg[1 + 3 * nb + a] = gx[a];
+        if (pnp) dg[1 + 3 * nb + 3] = gw;
     }
 }
 
@@ -1950,7 +2145,7 @@ static void env_obs(const pmgo_env* e, const World* w, float* obs, float* pol, f
     }
     int jo = e->cfg.joint_control ? 7 : 0;
     int G = e->dims.goal_dim;
-    double o[160], p[64];
+    double o[160], p[96];
     int no = 0, np = 0;
     if (jo) for (int d = 0; d < 7; d++) { o[no++] = w->q[d]; p[np++] = w->q[d]; }
     if (e->multi) {
@@ -1965,11 +2160,21 @@ static void env_obs(const pmgo_env* e, const World* w, float* obs, float* pol, f
             for (int a = 0; a < 4; a++) o[no++] = bl->quat[a];
             for (int a = 0; a < 3; a++) o[no++] = tv[a] - bl->vel[a];
             for (int a = 0; a < 3; a++) o[no++] = tw[a] - bl->omg[a];
-            if (ag) for (int a = 0; a < 3; a++) ag[3 * b + a] = (float)bl->pos[a];
+            if (ag) for (int a = 0; a < 3; a++) ag[(e->chest >= 0) + 3 * b + a] = (float)bl->pos[a];
+        }
+        if (e->chest >= 0) { /* :289-298 + chest.py:47-57: door joint state, then xyz + velocity of the three key points */
+            o[no++] = DOOR_Q(w); o[no++] = DOOR_QD(w);
+            p[np++] = DOOR_Q(w);
+            for (int kp = 0; kp < 3; kp++) {
+                for (int a = 0; a < 3; a++) { double x = e->door_c0[a] + e->door_axis[a] * DOOR_Q(w) + e->keypoint[kp][a]; o[no++] = x; p[np++] = x; }
+                for (int a = 0; a < 3; a++) { double v = e->door_axis[a] * DOOR_QD(w); o[no++] = v; p[np++] = v; }
+            }
+            if (ag) ag[0] = (float)DOOR_Q(w);
         }
         if (ag && e->cfg.grip_informed_goal) { /* :300-304 */
-            for (int a = 0; a < 3; a++) ag[3 * e->nb + a] = (float)tip[a];
-            ag[3 * e->nb + 3] = (float)closeness;
+            int g0 = (e->chest >= 0) + 3 * e->nb;
+            for (int a = 0; a < 3; a++) ag[g0 + a] = (float)tip[a];
+            if (e->grasping) ag[g0 + 3] = (float)closeness;
         }
         for (int i = 0; i < no; i++) o[i] = o[i] < -5 ? -5 : (o[i] > 5 ? 5 : o[i]);  /* :306-307 */
         for (int i = 0; i < np; i++) p[i] = p[i] < -5 ? -5 : (p[i] > 5 ? 5 : p[i]);
@@ -2034,6 +2239,8 @@ static void env_step_one(const pmgo_env* e, World* w, const float* a)
     for (int d = 0; d < 7; d++) { w->motor_target[d] = poses[d]; w->motor_maximp[d] = ARM_FORCE * PHYSICS_DT; } /* :222, :282-290 */
     w->arm_enabled = 1;
     for (int s = 0; s < SIM_STEPS; s++) step_simulation(e, w);                         /* :223-225 */
+    /* _get_obs keeps a door it finds open open: from now on the position motor holds it (:296-298) */
+    if (e->chest >= 0 && RFABS(e->door_open - DOOR_Q(w)) <= (real)0.01) DOOR_MOTOR(w) = 1;
     w->elapsed++;
 }
 
@@ -2067,10 +2274,22 @@ static int fill_dims(const pmg_config* c, pmg_dims* d)
         }
         break;
     }
+    case PMG_TASK_CHEST_PUSH:
+    case PMG_TASK_CHEST_PICK_AND_PLACE: {
+        /* kuka_multi_step_base_env.py:283-304: the multi-block layout + door joint pos / vel + 3 key points x (xyz, vel);
+         * goals lead with the door state.  The chest curricula (kuka_multi_step_envs.py:344-383, 477-517) are not built */
+        if (c->num_block < 1 || c->num_block > NBMAX || c->use_curriculum) return -1;
+        int gr = c->task == PMG_TASK_CHEST_PICK_AND_PLACE;
+        d->action_dim = (jo ? 7 : 3) + gr; d->observation_dim = 8 + 16 * c->num_block + jo + 20;
+        d->policy_state_dim = 4 + 3 * c->num_block + jo + 19; d->goal_dim = 1 + 3 * c->num_block;
+        if (c->grip_informed_goal) d->goal_dim += gr ? 4 : 3;   /* :300-304 */
+        break;
+    }
     default: return -1;
     }
-    if (c->task != PMG_TASK_BLOCK_STACK && c->task != PMG_TASK_BLOCK_REARRANGE && (c->use_curriculum || c->task_decomposition || c->grip_informed_goal)) return -1;
-    int multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE;
+    int chest = c->task == PMG_TASK_CHEST_PUSH || c->task == PMG_TASK_CHEST_PICK_AND_PLACE;
+    if (c->task != PMG_TASK_BLOCK_STACK && c->task != PMG_TASK_BLOCK_REARRANGE && !chest && (c->use_curriculum || c->task_decomposition || c->grip_informed_goal)) return -1;
+    int multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE || chest;
     int nb = c->task == PMG_TASK_REACH ? 0 : (multi ? c->num_block : 1);
     d->state_dim = 64 + 13 * nb + (c->use_curriculum ? 16 : 0);
     d->packed_dim = d->observation_dim + d->policy_state_dim + 2 * d->goal_dim + 3;
@@ -2166,14 +2385,16 @@ int pmgo_step(pmgo_env* e, const float* actions, float* obs, float* pol, float* 
             Kin k; kinematics(w->q, &k);
             for (int g = 0; g < 3; g++) a64[g] = k.p[PMG_BL_TIP][g];
         } else {
+            int c0 = e->chest >= 0;
+            if (c0) a64[0] = DOOR_Q(w);
             for (int b = 0; b < e->nb; b++)
-                for (int g = 0; g < 3; g++) a64[3 * b + g] = w->blk[b].pos[g];
+                for (int g = 0; g < 3; g++) a64[c0 + 3 * b + g] = w->blk[b].pos[g];
             if (e->cfg.grip_informed_goal) {
                 Kin k; kinematics(w->q, &k);
                 real dd[3];
                 v3sub(dd, k.p[PMG_BL_TAB1], k.p[PMG_BL_TAB2]);
-                for (int g = 0; g < 3; g++) a64[3 * e->nb + g] = k.p[PMG_BL_TIP][g];
-                a64[3 * e->nb + 3] = v3norm(dd);
+                for (int g = 0; g < 3; g++) a64[c0 + 3 * e->nb + g] = k.p[PMG_BL_TIP][g];
+                if (e->grasping) a64[c0 + 3 * e->nb + 3] = v3norm(dd);
             }
         }
         float r; uint8_t ok;
@@ -2266,6 +2487,7 @@ int pmgo_set_state(pmgo_env* e, const float* state)
 int pmgo_set_goal(pmgo_env* e, const uint8_t* mask, const float* goals)
 {
     int G = e->dims.goal_dim;
+    if (e->chest >= 0) { snprintf(e->err, sizeof(e->err), "pmgo_set_goal: the chest tasks have no static target"); return PMG_E_INVALID; }
     for (int i = 0; i < e->cfg.num_envs; i++)
         if (!mask || mask[i])
             for (int g = 0; g < G && g < 15; g++) e->w[i].goal[g] = goals[(size_t)i * G + g]; /* static targets only */
@@ -2276,7 +2498,7 @@ int pmgo_set_goal(pmgo_env* e, const uint8_t* mask, const float* goals)
 int pmgo_set_sub_goal(pmgo_env* e, const uint8_t* mask, int32_t ind)
 {
     if (!e->cfg.task_decomposition) { snprintf(e->err, sizeof(e->err), "pmgo_set_sub_goal: task_decomposition is off"); return PMG_E_STATE; }
-    int steps = e->cfg.grip_informed_goal ? 2 * e->nb : e->nb; /* kuka_multi_step_envs.py:13-17 */
+    int steps = e->chest >= 0 ? chest_num_steps(e) : (e->cfg.grip_informed_goal ? 2 * e->nb : e->nb); /* kuka_multi_step_envs.py:13-17 */
     if (ind < -1 || ind >= steps) { snprintf(e->err, sizeof(e->err), "pmgo_set_sub_goal: index %d out of range", ind); return PMG_E_INVALID; }
     for (int i = 0; i < e->cfg.num_envs; i++)
         if (!mask || mask[i]) e->w[i].level = ind < 0 ? steps - 1 : ind;

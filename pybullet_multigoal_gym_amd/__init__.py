@@ -13,7 +13,8 @@ _TASKS = ['push', 'reach', 'slide', 'pick_and_place',
           'block_stack', 'block_rearrange', 'chest_pick_and_place', 'chest_push',
           'primitive_push_assemble', 'primitive_push_reach', 'insertion']
 _GRIPPERS = ['robotiq85', 'parallel_jaw']
-_ACCELERATED = ['reach', 'push', 'slide', 'pick_and_place', 'block_stack', 'block_rearrange']
+_ACCELERATED = ['reach', 'push', 'slide', 'pick_and_place', 'block_stack', 'block_rearrange', 'chest_push',
+                'chest_pick_and_place']
 
 
 def make_env(task='reach', gripper='parallel_jaw', num_block=5, render=False, binary_reward=True,
@@ -51,8 +52,12 @@ def make_env(task='reach', gripper='parallel_jaw', num_block=5, render=False, bi
         if task == 'block_rearrange':   # kuka_multi_step_envs.py:158-159
             assert not task_decomposition, 'Block rearranging task does not support task decomposition.'
             assert not grip_informed_goal, 'Block rearranging task does not support gripper informed goal representation.'
+    elif task in ('chest_push', 'chest_pick_and_place'):
+        assert num_block <= 5, "only support up to 5 blocks"
+        if use_curriculum:
+            unsupported('use_curriculum on the chest tasks')
     elif task_decomposition or use_curriculum or grip_informed_goal:
-        unsupported('task_decomposition / use_curriculum / grip_informed_goal outside block_stack and block_rearrange')
+        unsupported('task_decomposition / use_curriculum / grip_informed_goal outside the multi-block tasks')
     return KukaVecEnv(task=task, num_envs=num_envs, binary_reward=binary_reward, joint_control=joint_control,
                       max_episode_steps=max_episode_steps, distance_threshold=distance_threshold, num_block=num_block,
                       seed=seed, seed_stride=seed_stride, device=device, env_index_offset=env_index_offset,

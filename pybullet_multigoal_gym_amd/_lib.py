@@ -11,7 +11,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIBRARY = os.path.join(_HERE, 'csrc', 'libpmg_hip.so')
 
-TASK_IDS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4, 'block_rearrange': 5}
+TASK_IDS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4, 'block_rearrange': 5,
+            'chest_push': 6, 'chest_pick_and_place': 7}
 PMG_BUF_PACKED = 7
 PMG_BUF_STATE = 8
 PMG_BUF_SCHED = 9

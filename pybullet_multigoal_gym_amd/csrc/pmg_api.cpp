@@ -156,9 +156,21 @@ int fill_dims(const pmg_config* c, pmg_dims* d, int* nb_out)
             d->goal_dim += 4;                               /* tip xyz + finger width, kuka_multi_step_base_env.py:300-304 */
         }
         break;
+    case PMG_TASK_CHEST_PUSH:
+    case PMG_TASK_CHEST_PICK_AND_PLACE: {
+        /* kuka_multi_step_base_env.py:283-304: the multi-block layout + door joint pos / vel + 3 key points x (xyz, vel);
+         * goals lead with the door state.  The chest curricula (kuka_multi_step_envs.py:344-383, 477-517) are not built */
+        if (c->num_block < 1 || c->num_block > 5 || c->use_curriculum) return -1;
+        const int gr = c->task == PMG_TASK_CHEST_PICK_AND_PLACE ? 1 : 0;
+        d->action_dim = (jo ? 7 : 3) + gr; d->observation_dim = 8 + 16 * c->num_block + jo + 20;
+        d->policy_state_dim = 4 + 3 * c->num_block + jo + 19; d->goal_dim = 1 + 3 * c->num_block;
+        if (c->grip_informed_goal) d->goal_dim += gr ? 4 : 3;
+        break;
+    }
     default: return -1;
     }
-    bool multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE;
+    bool multi = c->task == PMG_TASK_BLOCK_STACK || c->task == PMG_TASK_BLOCK_REARRANGE || c->task == PMG_TASK_CHEST_PUSH ||
+                 c->task == PMG_TASK_CHEST_PICK_AND_PLACE;
     if (!multi && (c->use_curriculum || c->task_decomposition || c->grip_informed_goal)) return -1;
     int nb = c->task == PMG_TASK_REACH ? 0 : (multi ? c->num_block : 1);
     *nb_out = nb;
@@ -174,12 +186,13 @@ void fill_params(pmg_env* e)
     const pmg_config& c = e->cfg;
     int t = c.task;
     P.n_envs = c.num_envs; P.task = t; P.nb = e->nb;
-    P.grasping = (t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
+    P.chest = t == PMG_TASK_CHEST_PUSH ? 0 : (t == PMG_TASK_CHEST_PICK_AND_PLACE ? 1 : -1);
+    P.grasping = (t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_CHEST_PICK_AND_PLACE);
     P.has_obj = (t != PMG_TASK_REACH);
-    P.in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK);
+    P.in_air = (t == PMG_TASK_REACH || t == PMG_TASK_PICK_AND_PLACE || t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_CHEST_PICK_AND_PLACE);
     P.joint_control = c.joint_control; P.binary_reward = c.binary_reward; P.max_steps = c.max_episode_steps;
     P.random_order = c.random_order;
-    P.multi = (t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_BLOCK_REARRANGE);
+    P.multi = (t == PMG_TASK_BLOCK_STACK || t == PMG_TASK_BLOCK_REARRANGE || P.chest >= 0);
     P.curriculum = c.use_curriculum; P.curriculum_update = 0;
     P.decomposition = c.task_decomposition; P.grip_goal = c.grip_informed_goal;
     {
@@ -189,9 +202,10 @@ void fill_params(pmg_env* e)
     P.adim = e->dims.action_dim; P.odim = e->dims.observation_dim; P.pdim = e->dims.policy_state_dim;
     P.gdim = e->dims.goal_dim; P.packed = e->dims.packed_dim;
     P.thr = c.distance_threshold;
-    bool on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE || t == PMG_TASK_BLOCK_REARRANGE); /* kuka_multi_step_envs.py:169 */
+    bool on_table = (t == PMG_TASK_PUSH || t == PMG_TASK_SLIDE || t == PMG_TASK_BLOCK_REARRANGE || t == PMG_TASK_CHEST_PUSH); /* kuka_multi_step_envs.py:169,399 */
     double range = 0.15, trange = 0.15;
     if (t == PMG_TASK_SLIDE) { range = 0.1; trange = 0.2; } /* kuka_single_step_base_env.py:66-69 */
+    if (P.chest >= 0) range = 0.1;                          /* kuka_multi_step_envs.py:251,400 */
     P.tip_init[0] = -0.52; P.tip_init[1] = 0.0; P.tip_init[2] = 0.25;
     if (on_table) P.tip_init[2] = 0.175 + 0.001;
     const double hi[3] = {-0.37, 0.20, 0.55}, lo[3] = {-0.67, -0.20, 0.175};
@@ -203,6 +217,10 @@ void fill_params(pmg_env* e)
     P.obj_lo[0] += 0.03; P.obj_hi[0] -= 0.03;
     P.tgt_lo[0] += 0.03; P.tgt_hi[0] -= 0.03;
     P.tgt_lo[2] = lo[2];
+    if (P.chest >= 0) { /* kuka_multi_step_base_env.py:102-105 */
+        P.obj_lo[0] += 0.05; P.obj_hi[0] += 0.05;
+        P.obj_lo[1] -= 0.05; P.obj_hi[1] += 0.05;
+    }
     P.obj_z = 0.175;
     const float th[3] = PMG_TABLE_HALF;
     P.table_c[0] = -0.52f; P.table_c[1] = 0.f; P.table_c[2] = 0.08f;
@@ -562,6 +580,7 @@ int pmg_set_state(pmg_env* e, const float* state)
 int pmg_set_goal(pmg_env* e, const uint8_t* mask, const float* goals)
 {
     if (!e || !goals) return PMG_E_INVALID;
+    if (e->P.chest >= 0) return fail(e, PMG_E_INVALID, "pmg_set_goal: the chest tasks have no static target");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     size_t N = (size_t)e->dims.num_envs;
     int G = e->dims.goal_dim;
@@ -578,7 +597,8 @@ int pmg_set_sub_goal(pmg_env* e, const uint8_t* mask, int32_t sub_goal_ind)
 {
     if (!e) return PMG_E_INVALID;
     if (!e->cfg.task_decomposition) return fail(e, PMG_E_STATE, "pmg_set_sub_goal: the handle was created without task_decomposition");
-    const int steps = e->cfg.grip_informed_goal ? 2 * e->nb : e->nb; /* kuka_multi_step_envs.py:13-17 */
+    int steps = e->cfg.grip_informed_goal ? 2 * e->nb : e->nb; /* kuka_multi_step_envs.py:13-17 */
+    if (e->P.chest >= 0) steps = (e->cfg.grip_informed_goal ? e->nb * (e->P.grasping ? 3 : 2) : e->nb) + 1; /* :238-242, 388-392 */
     if (sub_goal_ind < -1 || sub_goal_ind >= steps) return fail(e, PMG_E_INVALID, "pmg_set_sub_goal: index %d out of range [-1, %d)", sub_goal_ind, steps);
     if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_set_sub_goal: reset first");
     HIP_TRY(e, hipSetDevice(e->cfg.device));

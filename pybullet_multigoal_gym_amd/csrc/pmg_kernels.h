@@ -20,6 +20,8 @@ struct EnvParams {
     int multi;              /* multi-block observation layout: block_stack / block_rearrange */
     int curriculum, curriculum_update; /* kuka_multi_step_base_env.py:121-152 */
     int decomposition, grip_goal;      /* task_decomposition, grip_informed_goal (goal = blocks | tip target | finger width) */
+    int chest;                         /* -1, or the chest of chest_push (0: front sliding door) / chest_pick_and_place (1: lid);
+                                          the door's joint position, velocity and motor latch live in goal[0..2] */
     double goals_per_curriculum;
     int adim, odim, pdim, gdim, packed;
     float thr;
@@ -68,7 +70,7 @@ using pmgx::EnvParams;
 namespace pmg {
 
 /* one env per wavefront: the workgroup's LDS holds this env's contact store and the lane-constant table */
-template <int NB, int MAXC, bool CYL>
+template <int NB, int MAXC, int CYL>
 __device__ __forceinline__ void step_env(const EnvParams& P, const float* actions, int env)
 {
     __shared__ ContactLds<NB, MAXC> L;
@@ -316,7 +318,13 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
         int order[5] = {0, 1, 2, 3, 4};
         /* sub_goal_ind = -1 after reset (kuka_multi_step_base_env.py:248-249): the last sub-goal */
         int level = (P.grip_goal && P.decomposition) ? 2 * P.nb - 1 : P.nb - 1, moved = (1 << P.nb) - 1;
-        if (P.task == PMG_TASK_BLOCK_STACK) {
+        if (P.chest >= 0) {
+            /* chest_robot.robot_specific_reset (kuka_multi_step_base_env.py:242-243): door closed, at rest, motor off; the
+             * goal is the chest itself, nothing is drawn.  sub_goal_ind = -1 = the last of num_steps
+             * (kuka_multi_step_envs.py:238-242, 388-392) */
+            for (int a = 0; a < GOAL_DIM; a++) g[a] = 0.f;
+            level = (P.grip_goal ? P.nb * (P.grasping ? 3 : 2) : P.nb);
+        } else if (P.task == PMG_TASK_BLOCK_STACK) {
             if (P.random_order)
                 for (int i = P.nb - 1; i >= 1; i--) {
                     unsigned j = mt_interval(mt, (unsigned)i);

@@ -14,7 +14,7 @@
 
 /* three LDS footprints: reach (no blocks), one object (push / pick_and_place / slide), block_stack (<= 5 blocks);
  * CYL: the one object is the slide puck (cylinder x box pairs, anisotropic inertia) */
-template <int NB, int MAXC, bool CYL>
+template <int NB, int MAXC, int CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParams P, const float* __restrict__ actions)
 {
     pmg::step_env<NB, MAXC, CYL>(P, actions, pmg::scheduled_env(P, (int)blockIdx.x));
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) pmg_k_reward_flat(const float* __restrict
                                                         float thr, int binary, float* __restrict__ reward,
                                                         unsigned char* __restrict__ ok)
 {
-    __shared__ float part[256 * 19];
+    __shared__ float part[256 * 20];
     const int t = (int)threadIdx.x;
     const int wpi = G / VEC;                                   /* words per item */
     for (long long base = (long long)blockIdx.x * 256; base < B; base += (long long)gridDim.x * 256) {
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvP
  * 48-contact store; list 1 = the rest with a 30-contact store (20 KB of LDS instead of 29: 8 workgroups per CU instead
  * of 5).  The two launches run concurrently on two streams; a list-1 env that overflows is queued for the redo pass */
 constexpr int MULTI_SMALL_MAXC = 30;
-template <int NB, int MAXC, int LIST, bool CYL = false>
+template <int NB, int MAXC, int LIST, int CYL = 0>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmg::ContactLds<NB, MAXC> L;
@@ -186,6 +186,12 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_multi(pmg::En
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
                            hipEvent_t ev_fork, hipEvent_t ev_join)
 {
+    if (P.chest >= 0) {
+        /* chest tasks: one env per wavefront with the chest layout (door slot + chest pairs, 47 KB of LDS) */
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step<6, 48, 2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step<6, 48, 3>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        return hipGetLastError();
+    }
     if (P.nb > 1 && packed) {
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
@@ -239,6 +245,8 @@ __global__ void __launch_bounds__(256) pmg_k_sub_goal(pmg::EnvParams P, const un
     if (i == 31) { cold[7] = (float)level; return; }
     if (i >= P.gdim) return;
     v = pmg::effective_goal_at_level(P, env, i, level); /* level passed in, not read back: thread 31 may not have stored it yet */
+    /* chest sub-goal 0: the gripper goal is the gripper's current pose = the tail of the achieved goal of the last observation */
+    if (P.chest >= 0 && P.grip_goal && level == 0 && i >= 1 + 3 * P.nb) v = P.out[(size_t)env * P.packed + P.odim + P.pdim + i];
     P.out[(size_t)env * P.packed + P.odim + P.pdim + P.gdim + i] = v;
 }
 hipError_t pmg_launch_sub_goal(const pmg::EnvParams& P, const unsigned char* d_mask, int level, hipStream_t s)
@@ -266,7 +274,7 @@ hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int 
                            (float4*)reward, (unsigned int*)ok);
         first = quads * 4;
     }
-    if (G > 3 && G <= 19 && B >= 256) {
+    if (G > 3 && G <= 20 && B >= 256) {
         long long want = (B + 255) / 256;
         unsigned grid = (unsigned)(want < 8192 ? want : 8192);
         bool vec4 = (G % 4 == 0) && ((((size_t)ag | (size_t)dg) & 15) == 0);

@@ -26,7 +26,8 @@ from ._lib import PmgHandle, TASK_IDS, default_library
 
 TASK_CLASS_NAMES = {'reach': 'KukaReachEnv', 'push': 'KukaPushEnv', 'pick_and_place': 'KukaPickAndPlaceEnv',
                     'slide': 'KukaSlideEnv', 'block_stack': 'KukaBlockStackEnv',
-                    'block_rearrange': 'KukaBlockRearrangeEnv'}
+                    'block_rearrange': 'KukaBlockRearrangeEnv', 'chest_push': 'KukaChestPushEnv',
+                    'chest_pick_and_place': 'KukaChestPickAndPlaceEnv'}
 
 
 class KukaVecEnv:
@@ -50,20 +51,24 @@ class KukaVecEnv:
         self.num_block = int(num_block)
         self.task_decomposition = bool(task_decomposition)
         self.curriculum = bool(use_curriculum)
-        multi = task in ('block_stack', 'block_rearrange')
+        chest = task in ('chest_push', 'chest_pick_and_place')
+        multi = task in ('block_stack', 'block_rearrange') or chest
         if self.task_decomposition:   # kuka_multi_step_base_env.py:123, kuka_multi_step_envs.py:159
             assert not self.curriculum, 'if using task decomposition, curriculum should be False, vice versa'
-            assert task == 'block_stack', 'task decomposition is accelerated for block_stack only'
+            assert task == 'block_stack' or chest, 'task decomposition is accelerated for block_stack and the chest tasks'
         if self.curriculum:
-            assert multi, 'curriculum is a block_stack / block_rearrange option'
+            assert multi and not chest, 'curriculum is accelerated for block_stack / block_rearrange'
             assert self.num_block >= 2, 'the curriculum schedule needs at least two blocks'
             warnings.warn("You will need to call env.activate_curriculum_update() before your training phase, "
                           "and env.deactivate_curriculum_update() before your evaluation phase.")
         self.curriculum_update = False
         self.grip_informed_goal = bool(grip_informed_goal)
         if self.grip_informed_goal:   # kuka_multi_step_envs.py:13-17,158
-            assert task == 'block_stack', 'gripper informed goals are accelerated for block_stack only'
+            assert task == 'block_stack' or chest, 'gripper informed goals are accelerated for block_stack and the chest tasks'
         self.num_steps = self.num_block * (2 if self.grip_informed_goal else 1) if multi else None
+        if chest:                     # kuka_multi_step_envs.py:238-242, 388-392
+            per_block = (3 if task == 'chest_pick_and_place' else 2) if self.grip_informed_goal else 1
+            self.num_steps = self.num_block * per_block + 1
         self.dtype = np.dtype(dtype)
         self._seed_stride = int(seed_stride)
         self.handle = PmgHandle(_library or default_library(), task=TASK_IDS[task], num_envs=self.num_envs,
@@ -187,6 +192,19 @@ class KukaVecEnv:
         if not self.task_decomposition:
             return None
         st = self.handle.get_state()
+        if self.task in ('chest_push', 'chest_pick_and_place'):
+            # kuka_multi_step_envs.py:285-342, 433-475: the goals depend on the live block / gripper poses; read each
+            # one off the library and put the active indices (state column 39) back
+            levels = st[:, 39].astype(int)
+            out = []
+            for k in range(self.num_steps):
+                self.handle.set_sub_goal(k, None)
+                g = self.handle.read_outputs()[3]
+                g = g.astype(self.dtype) if self.dtype != np.float32 else g.copy()
+                out.append(g if self.batched else g[0])
+            for lv in np.unique(levels):
+                self.handle.set_sub_goal(int(lv), levels == lv)
+            return out
         nb, n = self.num_block, len(st)
         rows = np.arange(n)
         order = st[:, 40:40 + nb].astype(int)

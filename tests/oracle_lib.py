@@ -12,7 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, 'oracle')
 
-TASKS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4, 'block_rearrange': 5}
+TASKS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack': 4, 'block_rearrange': 5, 'chest_push': 6, 'chest_pick_and_place': 7}
 
 
 class PmgConfig(C.Structure):

@@ -90,7 +90,8 @@ def test_compute_reward_batch(built):
 
 
 @pytest.mark.parametrize('task,kw', [('push', {}), ('pick_and_place', {}), ('pick_and_place', {'binary_reward': False}),
-                                     ('slide', {}), ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 3})])
+                                     ('slide', {}), ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 3}),
+                                     ('chest_push', {'num_block': 2}), ('chest_pick_and_place', {'num_block': 5, 'grip_informed_goal': True})])
 def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task, kw):
     """Contact-rich rollouts are chaotic and the PGS early exit makes velocities only ~3e-4 exact, so
     the HIP path is held to the float64 oracle within a small multiple of the oracle's OWN
@@ -159,6 +160,50 @@ def test_constructed_cylinder_contacts_match_oracle(built, scenario):
         assert (so[:, 65] > 0.055).all() and np.abs(so[:, 66] - 0.170).max() < 1e-3   # pushed along +y, still on the table
     else:
         assert (so[:, 66] > 0.25).mean() > 0.9                                          # held by the contacts
+    env.close()
+
+
+@pytest.mark.parametrize('task', ['chest_push', 'chest_pick_and_place'])
+def test_constructed_chest_contacts_match_oracle(built, task):
+    """Chest walls, the sliding door / lid and the gripper on the device, in configurations a random policy does not
+    reach in a few steps: a block thrown at the walls from inside the chest, another at the closed door (push) or dropped
+    on the lid (pick and place), the door itself moving, and the gripper driven at the door so that it drags it.
+    64 envs with slightly different offsets; poses against the oracle within its own float32-vs-float64 spread."""
+    N = 64
+    pnp = task == 'chest_pick_and_place'
+    env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, num_block=2)
+    ora = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=8, num_block=2)
+    o32 = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=8, num_block=2, f32=True)
+    ora.reset(), o32.reset()
+    env.reset(), ora.reset(), o32.reset()
+    st = ora.get_state().copy()
+    off = np.random.RandomState(2).uniform(-0.004, 0.004, (N, 2)).astype(np.float32)
+    st[:, 48] = 0.02; st[:, 49] = 0.15; st[:, 50] = 0.0
+    st[:, 64] = -0.65 + off[:, 0]; st[:, 65] = 0.03 + off[:, 1]; st[:, 66] = 0.19; st[:, 71:74] = [-0.3, 0.25, 0.0]
+    if pnp:
+        st[:, 77] = -0.65 + off[:, 1]; st[:, 78] = off[:, 0]; st[:, 79] = 0.30; st[:, 84:87] = 0
+    else:
+        st[:, 77] = -0.56 + off[:, 1]; st[:, 78] = -0.02 + off[:, 0]; st[:, 79] = 0.175; st[:, 84:87] = [-0.3, 0.0, 0.0]
+    env.set_state(st), ora.set_state(st), o32.set_state(st)
+    A = env.dims.action_dim
+    a = np.zeros((N, A), np.float32)
+    for t in range(10):
+        a[:, 0] = -1; a[:, 2] = 1 if t < 7 else 0
+        o, r, d, info = env.step(a)
+        a64, r64, _, _ = ora.step(a)
+        a32, r32, _, _ = o32.step(a)
+    err = np.abs(o['achieved_goal'] - a64['achieved_goal']).max(1)        # door joint + block positions
+    spread = np.abs(a32['achieved_goal'] - a64['achieved_goal']).max(1)
+    assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4, (np.percentile(err, 90), np.percentile(spread, 90))
+    tip_err = np.abs(o['observation'][:, :3] - a64['observation'][:, :3]).max(1)
+    assert np.percentile(tip_err, 90) < 1e-3
+    so = ora.get_state()
+    assert (so[:, 64] > -0.695).all() and (so[:, 64] < -0.6).all() and np.abs(so[:, 66] - 0.175).max() < 2e-3  # kept in by the walls
+    if pnp:
+        assert (so[:, 79] > 0.27).all()                                     # the dropped block rests on the lid
+    else:
+        assert (so[:, 77] > -0.58).all()                                    # kept out by the door
+    assert np.isfinite(o['observation']).all()
     env.close()
 
 

@@ -222,6 +222,58 @@ def main():
     for c in ['blue', 'green', 'purple', 'red', 'yellow']:
         assert obj('block_%s.urdf' % c) == model['block']
 
+    # ---- chests (P/assets/objects/chest_front_sliding_door.urdf: ChestPush, chest_up_sliding_door.urdf:
+    # ChestPickAndPlace; P/robots/chest.py:5-23).  Static walls (mass 0 base + fixed mass-0 children), one prismatic
+    # door link carrying the handle cylinder through a fixed joint, three mass-less key-point links.  Everything is
+    # expressed relative to the chest base frame, which is never rotated (chest.py:33). ----
+    def rpy_exact(r, p, y):
+        cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+        return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                         [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                         [-sp, cp * sr, cp * cr]])
+
+    def chest(fn):
+        r = ET.parse(os.path.join(REF, 'objects', fn)).getroot()
+        L = {l.get('name'): l for l in r.findall('link')}
+        J = {j.find('child').get('link'): j for j in r.findall('joint')}
+        def frame(name):   # pose of a link in the base frame at q = 0
+            if name not in J:
+                return np.zeros(3), np.eye(3)
+            j = J[name]
+            pp, pR = frame(j.find('parent').get('link'))
+            o = j.find('origin')
+            return pp + pR @ np.array(vec(o.get('xyz'))), pR @ rpy_exact(*vec(o.get('rpy')))
+        walls, door, handle = [], None, None
+        dj = J['chest_door']
+        assert dj.get('type') == 'prismatic'
+        for name, l in L.items():
+            col = l.find('collision')
+            if col is None:
+                continue
+            assert vec(col.find('origin').get('xyz')) == [0, 0, 0] and vec(col.find('origin').get('rpy')) == [0, 0, 0]
+            g = col.find('geometry')[0]
+            pos, R = frame(name)
+            if name == 'chest_door_handle':
+                handle = dict(c=pos, R=R, radius=float(g.get('radius')), halflen=float(g.get('length')) / 2,
+                              friction=float(l.find('contact/lateral_friction').get('value')))
+            elif name == 'chest_door':
+                assert np.allclose(R, np.eye(3))
+                door = dict(c=pos, half=[x / 2 for x in vec(g.get('size'))])
+            else:
+                assert np.allclose(R, np.eye(3)) and float(l.find('inertial/mass').get('value')) == 0
+                walls.append(dict(c=pos.tolist(), half=[x / 2 for x in vec(g.get('size'))]))
+        mass = sum(float(L[n].find('inertial/mass').get('value')) for n in ['chest_door', 'chest_door_handle'])
+        kps = [frame('chest_door_%s_keypoint' % k)[0] - door['c'] for k in ['left', 'right', 'handle']]  # chest.py:34-38
+        lim = dj.find('limit')
+        return dict(walls=walls, door_c=door['c'].tolist(), door_half=door['half'], axis=vec(dj.find('axis').get('xyz')),
+                    lower=float(lim.get('lower')), upper=float(lim.get('upper')), mass=mass,
+                    handle_c=(handle['c'] - door['c']).tolist(), handle_R=handle['R'].tolist(),
+                    handle_radius=handle['radius'], handle_halflen=handle['halflen'], handle_friction=handle['friction'],
+                    keypoints=[k.tolist() for k in kps])
+    model['chest'] = [chest('chest_front_sliding_door.urdf'), chest('chest_up_sliding_door.urdf')]
+    for c_ in model['chest']:
+        assert c_['lower'] == 0 and sorted(np.abs(c_['axis']).tolist()) == [0, 0, 1]
+
 
     # ---- the full multibody link list in PyBullet's depth-first order (base = 'plane'),
     # fixed joints kept as 0-dof links [BULLET-PRIOR: no URDF_MERGE_FIXED_LINKS] ----
@@ -335,6 +387,26 @@ def main():
         if o['mass'] > 0:
             H.append('#define PMG_%s_MASS %r' % (K, o['mass']))
             H.append('#define PMG_%s_INERTIA %s' % (K, arr(o['inertia'])))
+    ch = model['chest']
+    H.append('/* chests, index 0 = front sliding door (chest_push), 1 = up sliding lid (chest_pick_and_place); positions relative\n'
+             ' * to the chest base (kuka_multi_step_base_env.py:64), walls padded to 4 with zero-size boxes */')
+    H.append('#define PMG_CHEST_BASE {-0.7, 0.0, 0.21}')
+    H.append('#define PMG_CHEST_NWALL ' + arr([len(c_['walls']) for c_ in ch]))
+    pad = lambda w: w + [dict(c=[0.0, 0.0, -10.0], half=[0.0, 0.0, 0.0])] * (4 - len(w))
+    H.append('#define PMG_CHEST_WALL_C ' + arr([[w['c'] for w in pad(c_['walls'])] for c_ in ch]))
+    H.append('#define PMG_CHEST_WALL_HALF ' + arr([[w['half'] for w in pad(c_['walls'])] for c_ in ch]))
+    H.append('#define PMG_CHEST_DOOR_C ' + arr([c_['door_c'] for c_ in ch]) + '   /* door box centre at q = 0 */')
+    H.append('#define PMG_CHEST_DOOR_HALF ' + arr([c_['door_half'] for c_ in ch]))
+    H.append('#define PMG_CHEST_DOOR_AXIS ' + arr([c_['axis'] for c_ in ch]))
+    H.append('#define PMG_CHEST_DOOR_UPPER ' + arr([c_['upper'] for c_ in ch]))
+    H.append('#define PMG_CHEST_DOOR_MASS ' + arr([c_['mass'] for c_ in ch]) + '   /* door + handle (fixed joint) */')
+    H.append('#define PMG_CHEST_HANDLE_C ' + arr([c_['handle_c'] for c_ in ch]) + '   /* cylinder centre relative to the door centre */')
+    H.append('#define PMG_CHEST_HANDLE_R ' + arr([c_['handle_R'] for c_ in ch]) + '   /* rpy (0, 1.57, 0): the axis is the third column */')
+    H.append('#define PMG_CHEST_HANDLE_RADIUS ' + arr([c_['handle_radius'] for c_ in ch]))
+    H.append('#define PMG_CHEST_HANDLE_HALFLEN ' + arr([c_['handle_halflen'] for c_ in ch]))
+    H.append('#define PMG_CHEST_HANDLE_FRICTION %r' % ch[0]['handle_friction'])
+    H.append('#define PMG_CHEST_WALL_FRICTION 0.5   /* no <contact> tag: [BULLET-PRIOR] btCollisionObject default */')
+    H.append('#define PMG_CHEST_KEYPOINTS ' + arr([c_['keypoints'] for c_ in ch]) + '   /* left, right, handle (chest.py:34-38), relative to the door centre */')
     H.append('#endif')
     with open(OUT_H, 'w') as f:
         f.write('\n'.join(H) + '\n')

@@ -11,7 +11,8 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', 'prof_' + task)
 dst = os.path.join(root, 'gpurun_out', 'profiles')
 os.makedirs(dst, exist_ok=True)
-ALGO = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242}
+ALGO = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242,
+        'chest_push': 1334, 'chest_pick_and_place': 1338}
 
 stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
 if stats:

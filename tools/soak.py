@@ -8,7 +8,8 @@ import pybullet_multigoal_gym_amd as pmg
 
 N, T = 2048, 300
 for task, kw in [('reach', {}), ('reach', {'joint_control': True}), ('push', {}), ('slide', {}), ('pick_and_place', {}),
-                 ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 4}), ('push', {'joint_control': True})]:
+                 ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 4}), ('push', {'joint_control': True}),
+                 ('chest_push', {'num_block': 4}), ('chest_pick_and_place', {'num_block': 4})]:
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         env = pmg.make_env(task=task, num_envs=N, seed=1, seed_stride=1, **kw)
@@ -22,7 +23,7 @@ for task, kw in [('reach', {}), ('reach', {'joint_control': True}), ('push', {})
         bad += int((~np.isfinite(o['observation'])).sum())
         succ += int(info['goal_achieved'].sum())
         if task != 'reach':
-            ag = o['achieved_goal'].reshape(N, -1, 3)
+            ag = o['achieved_goal'][:, (1 if task.startswith('chest') else 0):].reshape(N, -1, 3)
             zmin = min(zmin, float(ag[..., 2].min())); zmax = max(zmax, float(ag[..., 2].max()))
             far += int((np.abs(ag[..., 0] + 0.6) > 0.6).sum() + (np.abs(ag[..., 1]) > 0.5).sum())
     print(json.dumps({'task': task, **kw, 'nonfinite': bad, 'success_rate': succ / (N * T), 'obj_z_range': [zmin, zmax], 'left_workspace': far}))
