@@ -1286,7 +1286,7 @@ typedef struct {
     real base_target[3];
     int level;               /* active curriculum level / sub-goal index (nb-1 = the full goal) */
     int moved;               /* rearrange curriculum: bit i = block i has a target */
-    double cur_prob[NBMAX], cur_count[NBMAX]; /* curriculum_prob, num_generated_goals_per_curriculum */
+    double cur_prob[NBMAX + 1], cur_count[NBMAX + 1]; /* curriculum_prob, num_generated_goals_per_curriculum (chest: nb + 1 levels) */
     int cur_goal_step;       /* curriculum_goal_step */
     Block blk[NBMAX];
     mt19937 rng;
@@ -1916,7 +1916,7 @@ static void stack_goal_from_order(const pmgo_env* e, World* w)
  * idx = cdf.searchsorted(random_sample(), side='right')  (tests/golden/curriculum.json pins it) */
 static int mt_choice_p(mt19937* rng, const double* p, int n)
 {
-    double cdf[NBMAX], acc = 0;
+    double cdf[NBMAX + 1], acc = 0;
     for (int i = 0; i < n; i++) { acc += p[i]; cdf[i] = acc; }
     for (int i = 0; i < n; i++) cdf[i] /= cdf[n - 1];
     double u = mt_double(rng);
@@ -1926,10 +1926,13 @@ static int mt_choice_p(mt19937* rng, const double* p, int n)
 }
 
 /* _update_curriculum_prob: kuka_multi_step_base_env.py:350-379 */
+/* num_curriculum: num_block (block_stack / block_rearrange, kuka_multi_step_envs.py:19,166), num_block + 1 (chest
+ * tasks, :253,402: level = how many blocks go into the chest, 0 = just open the door) */
+static int num_curriculum(const pmgo_env* e) { return e->chest >= 0 ? e->nb + 1 : e->nb; }
 static void update_curriculum_prob(const pmgo_env* e, World* w)
 {
-    int n = e->nb;
-    int fin[NBMAX], half[NBMAX];
+    int n = num_curriculum(e);
+    int fin[NBMAX + 1], half[NBMAX + 1];
     for (int i = 0; i < n; i++) {
         fin[i] = w->cur_count[i] >= e->goals_per_curriculum;
         half[i] = w->cur_count[i] >= e->goals_per_curriculum / 2;
@@ -1947,9 +1950,21 @@ static void update_curriculum_prob(const pmgo_env* e, World* w)
 /* curriculum level draw shared by both tasks: kuka_multi_step_envs.py:125-134, 199-213 */
 static void curriculum_new_target(const pmgo_env* e, World* w)
 {
-    int level = mt_choice_p(&w->rng, w->cur_prob, e->nb);
+    int level = mt_choice_p(&w->rng, w->cur_prob, num_curriculum(e));
     w->level = level;
     w->cur_goal_step = level * 25 + 50;
+    if (e->chest >= 0) {
+        /* kuka_multi_step_envs.py:351-357, 484-490: choice(arange(nb), size=level, replace=False) == permutation(nb)[:level]
+         * (the permutation is drawn even for size 0) */
+        int perm[NBMAX];
+        for (int i = 0; i < e->nb; i++) perm[i] = i;
+        for (int i = e->nb - 1; i >= 1; i--) {
+            uint32_t j = mt_interval(&w->rng, (uint32_t)i);
+            int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+        }
+        w->moved = 0;
+        for (int i = 0; i < level; i++) w->moved |= 1 << perm[i];
+    }
     if (e->cfg.task == PMG_TASK_BLOCK_REARRANGE) {
         /* np_random.choice(arange(nb), size=level+1, replace=False) == permutation(nb)[:level+1] (sorted after) */
         int perm[NBMAX];
@@ -2000,6 +2015,7 @@ static void task_reset_multi(const pmgo_env* e, World* w)
          * target: the goal is the chest (kuka_multi_step_envs.py:256-283, 405-431).  sub_goal_ind = -1 = the last step */
         for (int g = 0; g < 16; g++) w->goal[g] = 0;
         w->level = chest_num_steps(e) - 1;
+        if (e->cfg.use_curriculum) curriculum_new_target(e, w);
         return;
     }
     if (e->cfg.task == PMG_TASK_BLOCK_STACK) {
@@ -2097,6 +2113,9 @@ static void chest_goal(const pmgo_env* e, const World* w, double* dg)
             if (ph == 1) lifted = j;
             gw = ph == 2 ? 0.06 : 0.03;
         }
+    } else if (e->cfg.use_curriculum) { /* :359-381, 492-515: the chosen blocks go in; level 0 leaves the gripper where it is */
+        in_chest = w->moved;
+        tip_goal = w->level == 0;
     }
     dg[0] = e->door_open;
     for (int b = 0; b < nb; b++)
@@ -2277,8 +2296,8 @@ static int fill_dims(const pmg_config* c, pmg_dims* d)
     case PMG_TASK_CHEST_PUSH:
     case PMG_TASK_CHEST_PICK_AND_PLACE: {
         /* kuka_multi_step_base_env.py:283-304: the multi-block layout + door joint pos / vel + 3 key points x (xyz, vel);
-         * goals lead with the door state.  The chest curricula (kuka_multi_step_envs.py:344-383, 477-517) are not built */
-        if (c->num_block < 1 || c->num_block > NBMAX || c->use_curriculum) return -1;
+         * goals lead with the door state */
+        if (c->num_block < 1 || c->num_block > NBMAX || (c->use_curriculum && c->task_decomposition)) return -1;
         int gr = c->task == PMG_TASK_CHEST_PICK_AND_PLACE;
         d->action_dim = (jo ? 7 : 3) + gr; d->observation_dim = 8 + 16 * c->num_block + jo + 20;
         d->policy_state_dim = 4 + 3 * c->num_block + jo + 19; d->goal_dim = 1 + 3 * c->num_block;
@@ -2322,7 +2341,7 @@ int pmgo_create(const pmg_config* cfg, pmgo_env** out)
     }
     {
         double total = cfg->num_goals_to_generate > 0 ? (double)cfg->num_goals_to_generate : 1e6;
-        e->goals_per_curriculum = e->nb > 0 ? floor(total / e->nb) : total;   /* :139 */
+        e->goals_per_curriculum = e->nb > 0 ? floor(total / num_curriculum(e)) : total;   /* :139 */
     }
     *out = e;
     pmgo_seed(e, cfg->seed_base, cfg->seed_stride);
@@ -2443,8 +2462,9 @@ int pmgo_get_state(pmgo_env* e, float* state)
         s[39] = (float)w->level; s[63] = (float)w->moved;
         if (e->cfg.use_curriculum) {
             float* cs = s + 64 + 13 * e->nb;
-            for (int b = 0; b < NBMAX; b++) { cs[b] = (float)w->cur_prob[b]; cs[5 + b] = (float)w->cur_count[b]; }
-            cs[10] = (float)w->cur_goal_step;
+            int nc = num_curriculum(e), st = e->chest >= 0 ? 6 : 5;   /* prob | generated | goal_step */
+            for (int b = 0; b < nc; b++) { cs[b] = (float)w->cur_prob[b]; cs[st + b] = (float)w->cur_count[b]; }
+            cs[2 * st] = (float)w->cur_goal_step;
         }
         for (int b = 0; b < e->nb; b++) {
             const Block* bl = &w->blk[b];
@@ -2472,8 +2492,9 @@ int pmgo_set_state(pmgo_env* e, const float* state)
         w->level = (int)s[39]; w->moved = (int)s[63];
         if (e->cfg.use_curriculum) {
             const float* cs = s + 64 + 13 * e->nb;
-            for (int b = 0; b < NBMAX; b++) { w->cur_prob[b] = cs[b]; w->cur_count[b] = cs[5 + b]; }
-            w->cur_goal_step = (int)cs[10];
+            int nc = num_curriculum(e), st = e->chest >= 0 ? 6 : 5;
+            for (int b = 0; b < nc; b++) { w->cur_prob[b] = cs[b]; w->cur_count[b] = cs[st + b]; }
+            w->cur_goal_step = (int)cs[2 * st];
         }
         for (int b = 0; b < e->nb; b++) {
             Block* bl = &w->blk[b];
@@ -2517,9 +2538,10 @@ int pmgo_curriculum_read(pmgo_env* e, int32_t* level, int32_t* goal_step, float*
         const World* w = &e->w[i];
         if (level) level[i] = w->level;
         if (goal_step) goal_step[i] = w->cur_goal_step;
-        for (int b = 0; b < e->nb; b++) {
-            if (prob) prob[(size_t)i * e->nb + b] = (float)w->cur_prob[b];
-            if (generated) generated[(size_t)i * e->nb + b] = (float)w->cur_count[b];
+        int nc = num_curriculum(e);
+        for (int b = 0; b < nc; b++) {
+            if (prob) prob[(size_t)i * nc + b] = (float)w->cur_prob[b];
+            if (generated) generated[(size_t)i * nc + b] = (float)w->cur_count[b];
         }
     }
     return PMG_OK;

@@ -54,8 +54,6 @@ def make_env(task='reach', gripper='parallel_jaw', num_block=5, render=False, bi
             assert not grip_informed_goal, 'Block rearranging task does not support gripper informed goal representation.'
     elif task in ('chest_push', 'chest_pick_and_place'):
         assert num_block <= 5, "only support up to 5 blocks"
-        if use_curriculum:
-            unsupported('use_curriculum on the chest tasks')
     elif task_decomposition or use_curriculum or grip_informed_goal:
         unsupported('task_decomposition / use_curriculum / grip_informed_goal outside the multi-block tasks')
     return KukaVecEnv(task=task, num_envs=num_envs, binary_reward=binary_reward, joint_control=joint_control,

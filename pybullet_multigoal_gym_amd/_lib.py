@@ -185,7 +185,7 @@ class PmgHandle:
         self._check(self.L.lib.pmg_curriculum_update(self.h, C.c_int32(int(bool(enabled)))))
 
     def curriculum_read(self):
-        nb = self.cfg.num_block
+        nb = self.cfg.num_block + (1 if self.cfg.task in (TASK_IDS['chest_push'], TASK_IDS['chest_pick_and_place']) else 0)
         level, goal_step = np.empty(self.N, np.int32), np.empty(self.N, np.int32)
         prob, generated = np.empty((self.N, nb), np.float32), np.empty((self.N, nb), np.float32)
         self._check(self.L.lib.pmg_curriculum_read(self.h, _p(level), _p(goal_step), _p(prob), _p(generated)))

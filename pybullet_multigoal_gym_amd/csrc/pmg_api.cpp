@@ -159,8 +159,8 @@ int fill_dims(const pmg_config* c, pmg_dims* d, int* nb_out)
     case PMG_TASK_CHEST_PUSH:
     case PMG_TASK_CHEST_PICK_AND_PLACE: {
         /* kuka_multi_step_base_env.py:283-304: the multi-block layout + door joint pos / vel + 3 key points x (xyz, vel);
-         * goals lead with the door state.  The chest curricula (kuka_multi_step_envs.py:344-383, 477-517) are not built */
-        if (c->num_block < 1 || c->num_block > 5 || c->use_curriculum) return -1;
+         * goals lead with the door state; num_curriculum = num_block + 1 (kuka_multi_step_envs.py:253,402) */
+        if (c->num_block < 1 || c->num_block > 5 || (c->use_curriculum && c->task_decomposition)) return -1;
         const int gr = c->task == PMG_TASK_CHEST_PICK_AND_PLACE ? 1 : 0;
         d->action_dim = (jo ? 7 : 3) + gr; d->observation_dim = 8 + 16 * c->num_block + jo + 20;
         d->policy_state_dim = 4 + 3 * c->num_block + jo + 19; d->goal_dim = 1 + 3 * c->num_block;
@@ -197,7 +197,7 @@ void fill_params(pmg_env* e)
     P.decomposition = c.task_decomposition; P.grip_goal = c.grip_informed_goal;
     {
         double total = c.num_goals_to_generate > 0 ? (double)c.num_goals_to_generate : 1e6;
-        P.goals_per_curriculum = e->nb > 0 ? floor(total / e->nb) : total; /* kuka_multi_step_base_env.py:139 */
+        P.goals_per_curriculum = e->nb > 0 ? floor(total / (P.chest >= 0 ? e->nb + 1 : e->nb)) : total; /* kuka_multi_step_base_env.py:139 */
     }
     P.adim = e->dims.action_dim; P.odim = e->dims.observation_dim; P.pdim = e->dims.policy_state_dim;
     P.gdim = e->dims.goal_dim; P.packed = e->dims.packed_dim;
@@ -350,7 +350,8 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         CREATE_TRY(hipMemset(e->P.goal, 0, N * pmg::GOAL_DIM * sizeof(float)));
         if (e->P.curr) { /* start with the easiest goal as the only possible one (kuka_multi_step_base_env.py:133) */
             std::vector<float> cs(N * pmg::CURR_DIM, 0.f);
-            for (size_t i = 0; i < N; i++) { cs[i * pmg::CURR_DIM] = 1.f; cs[i * pmg::CURR_DIM + 10] = 50.f; }
+            const int NC = e->P.chest >= 0 ? 6 : 5;   /* row: prob[NC] | generated[NC] | goal_step */
+            for (size_t i = 0; i < N; i++) { cs[i * pmg::CURR_DIM] = 1.f; cs[i * pmg::CURR_DIM + 2 * NC] = 50.f; }
             CREATE_TRY(hipMemcpy(e->P.curr, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         CREATE_TRY(hipMemset(e->P.out, 0, N * dims.packed_dim * sizeof(float)));
@@ -632,10 +633,11 @@ int pmg_curriculum_read(pmg_env* e, int32_t* level, int32_t* goal_step, float* p
     HIP_TRY(e, hipMemcpy(cold.data(), e->P.cold, cold.size() * sizeof(float), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < N; i++) {
         if (level) level[i] = (int32_t)cold[i * pmg::COLD_DIM + 7];
-        if (goal_step) goal_step[i] = (int32_t)cs[i * pmg::CURR_DIM + 10];
-        for (int b = 0; b < e->nb; b++) {
-            if (prob) prob[i * e->nb + b] = cs[i * pmg::CURR_DIM + b];
-            if (generated) generated[i * e->nb + b] = cs[i * pmg::CURR_DIM + 5 + b];
+        const int ncur = e->P.chest >= 0 ? e->nb + 1 : e->nb, NC = e->P.chest >= 0 ? 6 : 5;
+        if (goal_step) goal_step[i] = (int32_t)cs[i * pmg::CURR_DIM + 2 * NC];
+        for (int b = 0; b < ncur; b++) {
+            if (prob) prob[i * ncur + b] = cs[i * pmg::CURR_DIM + b];
+            if (generated) generated[i * ncur + b] = cs[i * pmg::CURR_DIM + NC + b];
         }
     }
     return PMG_OK;

@@ -324,6 +324,7 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
              * (kuka_multi_step_envs.py:238-242, 388-392) */
             for (int a = 0; a < GOAL_DIM; a++) g[a] = 0.f;
             level = (P.grip_goal ? P.nb * (P.grasping ? 3 : 2) : P.nb);
+            moved = (1 << P.nb) - 1;
         } else if (P.task == PMG_TASK_BLOCK_STACK) {
             if (P.random_order)
                 for (int i = P.nb - 1; i >= 1; i--) {
@@ -368,38 +369,43 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
         if (P.curriculum) {
             /* level = np_random.choice(num_curriculum, p=curriculum_prob): normalised cdf, one double draw,
              * searchsorted(side='right')  (kuka_multi_step_envs.py:128, 202) */
+            /* num_curriculum levels: num_block, or num_block + 1 for the chest tasks (level = how many blocks go in);
+             * row layout prob[NC] | generated[NC] | goal_step with NC = 5 / 6 */
+            const int ncur = P.chest >= 0 ? P.nb + 1 : P.nb, NC = P.chest >= 0 ? 6 : 5;
             float* cs = P.curr + (size_t)env * CURR_DIM;
-            double cdf[5], acc = 0.0;
-            for (int i = 0; i < P.nb; i++) { acc += (double)cs[i]; cdf[i] = acc; }
+            double cdf[6], acc = 0.0;
+            for (int i = 0; i < ncur; i++) { acc += (double)cs[i]; cdf[i] = acc; }
             double u = mt_uniform(mt, 0.0, 1.0);
             level = 0;
-            while (level < P.nb && cdf[level] / acc <= u) level++;
-            if (level > P.nb - 1) level = P.nb - 1;
-            cs[10] = (float)(level * 25 + 50);
-            if (P.task == PMG_TASK_BLOCK_REARRANGE) { /* choice(arange(nb), size=level+1, replace=False) = permutation(nb)[:level+1] */
+            while (level < ncur && cdf[level] / acc <= u) level++;
+            if (level > ncur - 1) level = ncur - 1;
+            cs[2 * NC] = (float)(level * 25 + 50);
+            if (P.task == PMG_TASK_BLOCK_REARRANGE || P.chest >= 0) {
+                /* choice(arange(nb), size=level+1 (rearrange) / level (chest), replace=False) = permutation(nb)[:size] */
                 int perm[5] = {0, 1, 2, 3, 4};
                 for (int i = P.nb - 1; i >= 1; i--) {
                     unsigned j = mt_interval(mt, (unsigned)i);
                     int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
                 }
                 moved = 0;
-                for (int i = 0; i <= level; i++) moved |= 1 << perm[i];
+                const int take = P.chest >= 0 ? level : level + 1;
+                for (int i = 0; i < take; i++) moved |= 1 << perm[i];
             }
             if (P.curriculum_update) { /* _update_curriculum_prob: kuka_multi_step_base_env.py:350-379 */
-                cs[5 + level] += 1.f;
-                bool fin[5], half[5];
-                for (int i = 0; i < P.nb; i++) {
-                    fin[i] = (double)cs[5 + i] >= P.goals_per_curriculum;
-                    half[i] = (double)cs[5 + i] >= P.goals_per_curriculum / 2;
+                cs[NC + level] += 1.f;
+                bool fin[6], half[6];
+                for (int i = 0; i < ncur; i++) {
+                    fin[i] = (double)cs[NC + i] >= P.goals_per_curriculum;
+                    half[i] = (double)cs[NC + i] >= P.goals_per_curriculum / 2;
                     if (fin[i]) cs[i] = 0.f;
                 }
                 if (half[0] && !fin[0]) { cs[0] = 0.5f; cs[1] = 0.5f; }
-                for (int i = 1; i < P.nb - 1; i++)
+                for (int i = 1; i < ncur - 1; i++)
                     if (fin[i - 1] && !fin[i]) {
                         if (half[i]) { cs[i] = 0.5f; cs[i + 1] = 0.5f; }
                         else cs[i] = 1.f;
                     }
-                if (fin[P.nb - 2]) cs[P.nb - 1] = 1.f;
+                if (fin[ncur - 2]) cs[ncur - 1] = 1.f;
             }
         }
         for (int b = 0; b < 5; b++) cold[8 + b] = (float)order[b];

@@ -57,8 +57,8 @@ class KukaVecEnv:
             assert not self.curriculum, 'if using task decomposition, curriculum should be False, vice versa'
             assert task == 'block_stack' or chest, 'task decomposition is accelerated for block_stack and the chest tasks'
         if self.curriculum:
-            assert multi and not chest, 'curriculum is accelerated for block_stack / block_rearrange'
-            assert self.num_block >= 2, 'the curriculum schedule needs at least two blocks'
+            assert multi, 'curriculum is a multi-block task option'
+            assert self.num_block >= 2 or chest, 'the curriculum schedule needs at least two levels'
             warnings.warn("You will need to call env.activate_curriculum_update() before your training phase, "
                           "and env.deactivate_curriculum_update() before your evaluation phase.")
         self.curriculum_update = False

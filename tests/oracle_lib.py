@@ -147,7 +147,7 @@ class OracleEnv:
             raise RuntimeError(self.lib.pmgo_last_error(self.h).decode())
 
     def curriculum(self):
-        nb = self.cfg.num_block
+        nb = self.cfg.num_block + (1 if self.cfg.task in (TASKS['chest_push'], TASKS['chest_pick_and_place']) else 0)
         lv, gs = np.zeros(self.N, np.int32), np.zeros(self.N, np.int32)
         pr, gen = np.zeros((self.N, nb), np.float32), np.zeros((self.N, nb), np.float32)
         rc = self.lib.pmgo_curriculum_read(self.h, _fp(lv), _fp(gs), _fp(pr), _fp(gen))

@@ -207,6 +207,42 @@ def test_constructed_chest_contacts_match_oracle(built, task):
     env.close()
 
 
+@pytest.mark.parametrize('task', ['chest_push', 'chest_pick_and_place'])
+def test_chest_curriculum_and_sub_goals_on_device(built, task):
+    """num_block + 1 curriculum levels drawn per env on the device (level, moved blocks, counters, schedule) and the
+    sub-goal lists of the decomposed task, against the oracle, env by env."""
+    import warnings
+    N, nb = 96, 3
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, num_block=nb, use_curriculum=True, num_goals_to_generate=32)
+    ora = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=8, num_block=nb, use_curriculum=True, num_goals_to_generate=32)
+    ora.reset()
+    env.activate_curriculum_update(), ora.curriculum_update(True)
+    for _ in range(20):
+        o, oo = env.reset(), ora.reset()
+        c = ora.curriculum()
+        assert np.array_equal(o['desired_goal'], oo['desired_goal'])
+        assert np.array_equal(env.last_curriculum_level, c['level']) and np.array_equal(env.curriculum_prob, c['prob'])
+        assert np.array_equal(env.num_generated_goals_per_curriculum, c['generated'])
+    assert c['level'].max() == nb and env.curriculum_prob.shape == (N, nb + 1)
+    env.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, num_block=nb, task_decomposition=True, grip_informed_goal=True)
+    ora = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=8, num_block=nb, task_decomposition=True, grip_informed_goal=True)
+    ora.reset()
+    env.reset(), ora.reset()
+    a = np.random.RandomState(3).uniform(-1, 1, (N, env.dims.action_dim)).astype(np.float32)
+    env.step(a), ora.step(a)
+    for k in list(range(env.num_steps)) + [-1]:
+        g = env.set_sub_goal(k)
+        ora.set_sub_goal(k)
+        ref = ora.reset(mask=np.zeros(N, bool))['desired_goal']
+        assert np.abs(g - ref).max() < 2e-4, k          # live block / gripper poses after one step: float32 vs float64
+    env.close()
+
+
 def test_multistep_bookkeeping_on_device(built):
     """Curriculum draws / schedule against the numpy-generated golden vectors, and sub-goal switching against the
     oracle, through the HIP library (8 envs, seed_stride 0: every env replays the golden sequence)."""

@@ -41,7 +41,7 @@ def test_make_env_rejects_what_is_outside_the_hot_path(built):
         pmg.make_env(task='fly')
     with pytest.raises(AssertionError):
         pmg.make_env(task='reach', gripper='claw')
-    for kw in [dict(task='primitive_push_reach'), dict(task='insertion'), dict(task='chest_push', use_curriculum=True), dict(gripper='robotiq85'),
+    for kw in [dict(task='primitive_push_reach'), dict(task='insertion'), dict(gripper='robotiq85'),
                dict(render=True), dict(image_observation=True), dict(goal_image=True), dict(task_decomposition=True),
                dict(use_curriculum=True), dict(grip_informed_goal=True), dict(primitive='discrete_push')]:
         with pytest.raises(NotImplementedError):

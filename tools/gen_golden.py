@@ -184,6 +184,29 @@ def rearrange_reset(rs, nb, cur=None):
     return out
 
 
+def chest_reset(rs, nb, pnp, cur=None):
+    """kuka_multi_step_base_env.py:97-110, 221-250 (chest=True) + kuka_multi_step_envs.py:256-283, 344-383 (pick and
+    place) / 405-431, 477-517 (push): blocks in the shifted object box, no random target, num_block + 1 curriculum levels."""
+    tip = np.array([-0.52, 0.0, 0.25 if pnp else 0.175 + 0.001])
+    obj_lo, obj_hi = tip.copy() - 0.1, tip.copy() + 0.1
+    obj_lo[0] += 0.03; obj_hi[0] -= 0.03
+    obj_lo[0] += 0.05; obj_hi[0] += 0.05; obj_lo[1] -= 0.05; obj_hi[1] += 0.05
+    poses = multi_blocks(rs, nb, tip, obj_lo, obj_hi)
+    centre = np.array([-0.7, 0.0, 0.21]); centre[0] += 0.05; centre[2] = 0.175
+    out = {'blocks': [p.tolist() for p in poses]}
+    door = [0.10 if pnp else 0.12]
+    if cur is None:
+        out['desired_goal'] = np.concatenate([door] + [centre] * nb).tolist()
+        return out
+    level = cur.draw(rs)
+    moved = np.sort(rs.choice(np.arange(nb), size=level, replace=False), kind='stable').tolist()
+    cur.account(level)
+    dg = [door] + [centre if i in moved else poses[i] for i in range(nb)]
+    out.update({'level': level, 'goal_step': level * 25 + 50, 'moved': [int(m) for m in moved],
+                'desired_goal': np.concatenate(dg).tolist(), 'prob': cur.prob.tolist(), 'generated': cur.count.tolist()})
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     rng = {}
@@ -239,6 +262,17 @@ def main():
             cur = Curriculum(nb, 8 * nb)
             multi['block_stack%d_curriculum/%d' % (nb, seed)] = episodes(lambda: stack_curriculum_reset(rs, nb, cur), 10 * nb)
     json.dump({'num_goals_to_generate_per_block': 8, 'episodes': multi}, open(os.path.join(OUT, 'multistep.json'), 'w'), indent=0)
+
+    chest = {}
+    for task, pnp in [('chest_push', False), ('chest_pick_and_place', True)]:
+        for nb in [1, 3, 5]:
+            for seed in [0, 3]:
+                rs, _ = gym_np_random(seed)
+                chest['%s%d/%d' % (task, nb, seed)] = [chest_reset(rs, nb, pnp) for _ in range(3)]
+                rs, _ = gym_np_random(seed)
+                cur = Curriculum(nb + 1, 8 * (nb + 1))
+                chest['%s%d_curriculum/%d' % (task, nb, seed)] = episodes(lambda: chest_reset(rs, nb, pnp, cur), 10 * (nb + 1))
+    json.dump({'num_goals_to_generate_per_level': 8, 'episodes': chest}, open(os.path.join(OUT, 'chest.json'), 'w'), indent=0)
 
     fk = {'rest_pose': [0, -0.5592432, 0, 1.733180, 0, -0.8501557, 0, 0.035, 0.035],
           'tip_position': [-0.522923, 0.0, 0.250773], 'tip_position_tol': 1e-5,
