@@ -62,6 +62,14 @@ __device__ __forceinline__ float row_sum(float v)
     v += dpp<0x140>(0.f, v); /* row_mirror */
     return v;
 }
+/* sum over each 8-lane half row (lanes 8h .. 8h+7), result in every lane of the half row */
+__device__ __forceinline__ float half_sum(float v)
+{
+    v += dpp<0xB1>(0.f, v);  /* quad_perm [1,0,3,2] */
+    v += dpp<0x4E>(0.f, v);  /* quad_perm [2,3,0,1] */
+    v += dpp<0x141>(0.f, v); /* row_half_mirror */
+    return v;
+}
 __device__ __forceinline__ float row_max(float v)
 {
     v = fmaxf(v, dpp<0xB1>(v, v));
@@ -147,6 +155,7 @@ __device__ __forceinline__ float row_shr(float v, float fill) { return wv::row_s
 template <int N>
 __device__ __forceinline__ float row_shl(float v, float fill) { return wv::row_shl<N>(v, fill); }
 __device__ __forceinline__ float row_sum(float v) { return wv::row_sum(v); }
+__device__ __forceinline__ float half_sum(float v) { return wv::half_sum(v); }
 __device__ __forceinline__ float row_max(float v) { return wv::row_max(v); }
 __device__ __forceinline__ float sum_row0(float v) { return wv::row_sum(v); } /* "row 0" = the caller's own row */
 __device__ __forceinline__ float max_row0(float v) { return wv::row_max(v); }

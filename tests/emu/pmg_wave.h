@@ -79,6 +79,15 @@ inline float row_sum(float v)
     exchange_done();
     return s;
 }
+inline float half_sum(float v)
+{
+    exchange_put<1>(&v);
+    int b = lane() & ~7;
+    /* same association order as the DPP butterfly: pairs inside the quads, then the two quads */
+    float s = ((xbuf()[b] + xbuf()[b + 1]) + (xbuf()[b + 2] + xbuf()[b + 3])) + ((xbuf()[b + 4] + xbuf()[b + 5]) + (xbuf()[b + 6] + xbuf()[b + 7]));
+    exchange_done();
+    return s;
+}
 inline float row_max(float v)
 {
     exchange_put<1>(&v);
@@ -155,6 +164,7 @@ inline float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }
 template <int N>
 inline float row_shl(float v, float fill) { return wv::row_shl<N>(v, fill); }
 inline float row_sum(float v) { return wv::row_sum(v); }
+inline float half_sum(float v) { return wv::half_sum(v); }
 inline float row_max(float v) { return wv::row_max(v); }
 inline float sum_row0(float v) { return wv::row_sum(v); }
 inline float max_row0(float v) { return wv::row_max(v); }
