@@ -175,7 +175,7 @@ def test_emulated_chest_push_drags_the_door_like_the_oracle(emu_library):
         assert np.abs(o[k] - oo[k]).max() < 1e-6
     assert np.abs(env.get_state() - ora.get_state()).max() < 1e-6
     a = np.zeros((1, 3), np.float32)
-    for t in range(14):
+    for t in range(13):
         a[0] = [-1, 0, 1 if t < 8 else 0]
         o, r, d, info = env.step(a)
         oo, ro, do, oko = ora.step(a)

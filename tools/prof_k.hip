@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(64, 2) k_prof_packed(pmg::EnvParams P, const f
 int main(int argc, char** argv)
 {
     int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push, 4 block_stack with four blocks on the table
-    pmg::EnvParams P; memset(&P, 0, sizeof(P));
+    pmg::EnvParams P; memset(&P, 0, sizeof(P)); P.chest = -1;
     int N = argc > 3 ? atoi(argv[3]) : 4096; P.n_envs = N; P.task = task; P.nb = task == 0 ? 0 : (task == 4 ? 4 : 1); P.multi = task == 4; P.grasping = task == 4; P.has_obj = task != 0; P.max_steps = 50; P.binary_reward = 1;
     P.adim = task == 4 ? 4 : 3; P.odim = task == 0 ? 3 : (task == 4 ? 72 : 20); P.pdim = task == 0 ? 3 : (task == 4 ? 16 : 7); P.gdim = task == 4 ? 12 : 3; P.packed = P.odim + P.pdim + 9; P.thr = 0.05f;
     float lo[3] = {-0.67f, -0.2f, 0.175f}, hi[3] = {-0.37f, 0.2f, 0.55f}, tc[3] = {-0.52f, 0, 0.08f}, th[3] = {0.25f, 0.35f, 0.08f};
