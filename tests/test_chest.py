@@ -315,3 +315,23 @@ def test_emulated_chest_curriculum_matches_numpy_golden(emu_library, task):
     assert np.abs(o['desired_goal'] - oo['desired_goal']).max() < 1e-6
     assert np.array_equal(o['desired_goal'][0, 7:], o['achieved_goal'][0, 7:])
     env.close()
+
+
+def test_emulated_finger_opens_the_door_by_its_handle(emu_library):
+    """What the task is about: the closed fingers come in over the door, next to the handle cylinder, and push it
+    sideways -- finger x handle (cylinder x box) contacts driving the door DoF.  The oracle flies the approach, the device
+    takes over from its state for the push."""
+    env = _quiet_env('chest_push', emu_library, num_block=1, seed=3)
+    ora = O.OracleEnv('chest_push', 1, num_block=1, seed_base=3, seed_stride=1, f32=True)
+    ora.reset(), env.reset(), ora.reset()
+    for a, n in (([0, 0, 1], 6), ([0, -1, 0], 3), ([-1, 0, 0], 7)):
+        for _ in range(n):
+            oo = ora.step(np.float32([a]))[0]
+    assert abs(oo['achieved_goal'][0, 0]) < 1e-3                  # about to touch: the door is still closed
+    env.set_state(ora.get_state())
+    for _ in range(3):
+        o = env.step(np.float32([[0, 1, 0]]))[0]
+        oo = ora.step(np.float32([[0, 1, 0]]))[0]
+        _compare(o, oo, 5e-2, 1e-4)   # poses tight; the velocities of a finger scraping along the handle are noisy
+    assert oo['achieved_goal'][0, 0] > 0.015                      # pushed open by almost 2 cm in three steps
+    env.close()

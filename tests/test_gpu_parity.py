@@ -207,6 +207,31 @@ def test_constructed_chest_contacts_match_oracle(built, task):
     env.close()
 
 
+def test_finger_opens_the_chest_door_by_its_handle(built):
+    """The closed fingers come in over the front door next to its handle and push it sideways: finger x handle
+    (cylinder x box) contacts drive the door DoF until the joint limit stops it and the motor latches."""
+    N = 32
+    env = pmg.make_env(task='chest_push', num_envs=N, seed=0, seed_stride=1, num_block=1)
+    ora = oracle_lib.OracleEnv('chest_push', N, seed_base=0, seed_stride=1, threads=8, num_block=1)
+    o32 = oracle_lib.OracleEnv('chest_push', N, seed_base=0, seed_stride=1, threads=8, num_block=1, f32=True)
+    ora.reset(), o32.reset()
+    env.reset(), ora.reset(), o32.reset()
+    rs = np.random.RandomState(4)
+    for a, n in (([0, 0, 1], 6), ([0, -1, 0], 3), ([-1, 0, 0], 7), ([0, 1, 0], 14)):
+        for _ in range(n):
+            act = np.clip(np.tile(np.float32(a), (N, 1)) + rs.uniform(-0.05, 0.05, (N, 3)).astype(np.float32), -1, 1)
+            o, r, d, info = env.step(act)
+            a64 = ora.step(act)[0]
+            a32 = o32.step(act)[0]
+    q = a64['achieved_goal'][:, 0]
+    assert (q > 0.1).all()                                          # every env opened its door
+    err = np.abs(o['achieved_goal'] - a64['achieved_goal']).max(1)
+    spread = np.abs(a32['achieved_goal'] - a64['achieved_goal']).max(1)
+    assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4, (np.percentile(err, 90), np.percentile(spread, 90))
+    assert np.array_equal(env.get_state()[:, 50], ora.get_state()[:, 50])   # the same envs latched the motor
+    env.close()
+
+
 @pytest.mark.parametrize('task', ['chest_push', 'chest_pick_and_place'])
 def test_chest_curriculum_and_sub_goals_on_device(built, task):
     """num_block + 1 curriculum levels drawn per env on the device (level, moved blocks, counters, schedule) and the
