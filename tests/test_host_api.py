@@ -94,3 +94,43 @@ def test_integration_stub_config_matches_the_header():
     body = hdr[hdr.index('typedef struct pmg_config {'):hdr.index('} pmg_config;')]
     names = re.findall(r'^\s+(?:u?int\d+_t|float)\s+(\w+)', body, re.M)
     assert names == [f[0] for f in PmgConfig._fields_]
+
+
+def test_edge_case_inputs(emu_library):
+    """Empty, ragged and degenerate inputs at the boundary (through the emulator build of the C ABI): an empty HER
+    batch, goals with leading axes [T, N, G], a single un-batched pair, a reset with an all-false mask, goals exactly
+    on the threshold, and shape errors raised before anything reaches the library."""
+    import pybullet_multigoal_gym_amd as pmg
+    env = pmg.make_env(task='reach', num_envs=3, seed=2, seed_stride=1, _library=emu_library)
+    o = env.reset()
+    r, ok = env._compute_reward(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert r.shape == (0,) and ok.shape == (0,)
+    ag = np.random.RandomState(0).uniform(-0.1, 0.1, (5, 7, 3)).astype(np.float32)
+    dg = np.zeros_like(ag)
+    r, ok = env._compute_reward(ag, dg)
+    d = np.linalg.norm(ag.astype(np.float64), axis=-1)
+    assert r.shape == (5, 7) and np.array_equal(ok, ~(d > 0.05)) and np.array_equal(r, -(d > 0.05).astype(np.float32))
+    r1, ok1 = env._compute_reward(ag[0, 0], dg[0, 0])
+    assert r1.shape == () and ok1.shape == () and r1 == r[0, 0]
+    # exactly on the threshold counts as achieved (not_achieved = d > threshold, kuka_single_step_base_env.py:240)
+    r2, ok2 = env._compute_reward(np.float32([[0.05, 0, 0]]), np.float32([[0, 0, 0]]))
+    assert ok2[0] and r2[0] == 0 and np.signbit(r2[0])                       # -0.0, as the reference's -float32(False)
+    with pytest.raises(ValueError):
+        env._compute_reward(np.zeros((4, 2), np.float32), np.zeros((4, 2), np.float32))
+    with pytest.raises(AssertionError):                                       # kuka_multi_step_base_env.py:339
+        env._compute_reward(np.zeros((4, 3), np.float32), np.zeros((5, 3), np.float32))
+    # a reset that selects nobody returns the current observations and leaves the state alone
+    st = env.get_state()
+    o2 = env.reset(mask=np.zeros(3, bool))
+    assert all(np.array_equal(o[k], o2[k]) for k in o) and np.array_equal(st, env.get_state())
+    with pytest.raises(AssertionError):
+        env.step(np.zeros((2, 3), np.float32))                                # ragged batch
+    with pytest.raises(AssertionError):
+        env.step(np.full((3, 3), 1.5, np.float32))                            # outside the action space (kuka.py:168)
+    env.close()
+    single = pmg.make_env(task='reach', seed=2, _library=emu_library)         # the reference's un-batched shapes
+    o1 = single.reset()
+    assert o1['observation'].shape == (3,) and o1['desired_goal'].shape == (3,)
+    ob, rr, dd, info = single.step(np.zeros(3, np.float32))
+    assert ob['achieved_goal'].shape == (3,) and isinstance(dd, bool) and isinstance(info['goal_achieved'], bool)
+    single.close()
