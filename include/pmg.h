@@ -68,7 +68,7 @@ typedef struct pmg_config {
     int32_t struct_size;
     int32_t task;               /* PMG_TASK_* */
     int32_t num_envs;           /* N: envs simulated by THIS handle (one GPU) */
-    int32_t num_block;          /* block_stack / block_rearrange only, 1..5 (P/__init__.py:108) */
+    int32_t num_block;          /* multi-block tasks (block_stack, block_rearrange, chest_*), 1..5 (P/__init__.py:108) */
     int32_t binary_reward;      /* P/__init__.py:4 */
     int32_t joint_control;      /* P/__init__.py:6 */
     int32_t max_episode_steps;  /* gym TimeLimit, P/__init__.py:6,105 */
@@ -78,11 +78,15 @@ typedef struct pmg_config {
     uint64_t seed_base;         /* env i is seeded with seed_base + i*seed_stride */
     uint64_t seed_stride;       /* 0 reproduces the reference (every env seed 0) */
     int32_t env_index_offset;   /* global index of this shard's env 0 (multi-GPU) */
-    int32_t task_decomposition; /* block_stack: sub-goals, kuka_multi_step_envs.py:89-122 (excludes use_curriculum) */
-    int32_t use_curriculum;     /* block_stack / block_rearrange: kuka_multi_step_base_env.py:121-140 (num_block >= 2) */
+    int32_t task_decomposition; /* block_stack, chest_*: sub-goals, kuka_multi_step_envs.py:89-122, 285-342, 433-475
+                                   (excludes use_curriculum) */
+    int32_t use_curriculum;     /* kuka_multi_step_base_env.py:121-140: num_block levels (block_stack / block_rearrange,
+                                   num_block >= 2) or num_block + 1 (chest_*: how many blocks go into the chest) */
     int32_t num_goals_to_generate; /* curriculum budget, P/__init__.py:11 (default 1e6); 0 = 1e6 */
     int32_t grip_informed_goal; /* block_stack: goals carry the gripper tip target + finger width (kuka_multi_step_envs.py:75-77);
-                                   goal_dim = 3*num_block + 4, sub-goals double (pick / place) */
+                                   goal_dim = 3*num_block + 4, sub-goals double (pick / place).  chest_*: goal_dim =
+                                   1 + 3*num_block (door joint first) + 3 (chest_push: tip) / + 4 (chest_pick_and_place: tip,
+                                   finger width); 2 / 3 sub-goals per block after "open the door" */
     int32_t reserved[3];
 } pmg_config;
 
@@ -147,11 +151,12 @@ int pmg_compute_reward_device(pmg_env* env, const float* d_achieved_goal, const 
 
 /* Checkpoint / test hooks (no reference equivalent).
  * state: [N, state_dim] float32, layout documented in DESIGN.md (with use_curriculum the row ends with 16
- * floats of curriculum state: prob[5] generated[5] goal_step). */
+ * floats of curriculum state: prob[5] generated[5] goal_step; chest tasks prob[6] generated[6] goal_step). */
 int pmg_get_state(pmg_env* env, float* state);
 int pmg_set_state(pmg_env* env, const float* state);
 /* Host-injected goal / object poses for seed-parity tests (replaces the RNG
- * draws of _generate_goal for the masked envs).  goals: [N, goal_dim]. */
+ * draws of _generate_goal for the masked envs).  goals: [N, goal_dim].  PMG_E_INVALID for the chest tasks (their goal
+ * is the chest: no static target; goal row [0..2] holds the door joint position, velocity and motor latch). */
 int pmg_set_goal(pmg_env* env, const uint8_t* mask, const float* goals);
 
 /* Multi-step task bookkeeping (block_stack / block_rearrange), per env -- the reference keeps one copy per
@@ -160,13 +165,16 @@ int pmg_set_goal(pmg_env* env, const uint8_t* mask, const float* goals);
  *
  * Replaces: KukaBulletMultiBlockEnv.set_sub_goal (kuka_multi_step_base_env.py:154-177): sub-goal index for
  * the masked envs (mask NULL = all), -1 = the final goal, as after reset; refreshes desired_goal in the output
- * buffers.  Valid indices: [-1, num_block), or [-1, 2*num_block) with grip_informed_goal (pick, place, pick, ...).  PMG_E_STATE unless the handle was created with task_decomposition. */
+ * buffers.  Valid indices: [-1, num_block), or [-1, 2*num_block) with grip_informed_goal (pick, place, pick, ...);
+ * chest tasks: [-1, num_steps) with num_steps = num_block + 1, or 2*num_block + 1 (chest_push) / 3*num_block + 1
+ * (chest_pick_and_place) with grip_informed_goal -- index 0 is "open the door" (kuka_multi_step_envs.py:238-242,
+ * 388-392).  PMG_E_STATE unless the handle was created with task_decomposition. */
 int pmg_set_sub_goal(pmg_env* env, const uint8_t* mask, int32_t sub_goal_ind);
 /* Replaces: activate_curriculum_update / deactivate_curriculum_update (kuka_multi_step_base_env.py:142-152). */
 int pmg_curriculum_update(pmg_env* env, int32_t enabled);
 /* Curriculum read-out, any pointer may be NULL: level [N] (last_curriculum_level), goal_step [N]
- * (curriculum_goal_step = level*25 + 50), prob [N, num_block] (curriculum_prob), generated [N, num_block]
- * (num_generated_goals_per_curriculum). */
+ * (curriculum_goal_step = level*25 + 50), prob [N, num_curriculum] (curriculum_prob), generated [N, num_curriculum]
+ * (num_generated_goals_per_curriculum); num_curriculum = num_block, or num_block + 1 for the chest tasks. */
 int pmg_curriculum_read(pmg_env* env, int32_t* level, int32_t* goal_step, float* prob, float* generated);
 
 /* Multi-GPU (no reference equivalent): one handle per
