@@ -91,7 +91,8 @@ def test_compute_reward_batch(built):
 
 @pytest.mark.parametrize('task,kw', [('push', {}), ('pick_and_place', {}), ('pick_and_place', {'binary_reward': False}),
                                      ('slide', {}), ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 3}),
-                                     ('chest_push', {'num_block': 2}), ('chest_pick_and_place', {'num_block': 5, 'grip_informed_goal': True})])
+                                     ('chest_push', {'num_block': 2}), ('chest_pick_and_place', {'num_block': 5, 'grip_informed_goal': True}),
+                                     ('chest_push', {'num_block': 3, 'joint_control': True}), ('block_stack', {'num_block': 5, 'joint_control': True})])
 def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task, kw):
     """Contact-rich rollouts are chaotic and the PGS early exit makes velocities only ~3e-4 exact, so
     the HIP path is held to the float64 oracle within a small multiple of the oracle's OWN
