@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 CONFIGS = [('reach', {}), ('push', {}), ('pick_and_place', {}), ('pick_and_place', {'binary_reward': False}),
-           ('slide', {}), ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 3})]
+           ('slide', {}), ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 3}),
+           ('chest_push', {'num_block': 2}), ('chest_pick_and_place', {'num_block': 2})]
 
 
 def capture(task, kw, T):
