@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pybullet_multigoal_gym_amd as pmg
 
-N, T = 2048, 300
+N, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (2048, 300)
 for task, kw in [('reach', {}), ('reach', {'joint_control': True}), ('push', {}), ('slide', {}), ('pick_and_place', {}),
                  ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 4}), ('push', {'joint_control': True}),
                  ('chest_push', {'num_block': 4}), ('chest_pick_and_place', {'num_block': 4})]:
