@@ -8,6 +8,7 @@
 template <int NB, int MAXC>
 __global__ void __launch_bounds__(64, 2) k_prof(pmg::EnvParams P, const float* act) { pmg::step_env<NB, MAXC, false>(P, act, pmg::scheduled_env(P, (int)blockIdx.x)); }
 __global__ void __launch_bounds__(64, 2) k_prof_packed(pmg::EnvParams P, const float* act) { pmgp::step_group(P, act, (int)blockIdx.x); }
+__global__ void __launch_bounds__(64, 2) k_prof_obj4(pmg::EnvParams P, const float* act) { __shared__ pmgp::ObjLds4 sm; pmgp::step_group_obj<false>(P, act, (int)blockIdx.x, sm); }
 int main(int argc, char** argv)
 {
     int task = argc > 1 ? atoi(argv[1]) : 0;  // 0 reach (tip low), 1 push, 4 block_stack with four blocks on the table
@@ -46,6 +47,12 @@ int main(int argc, char** argv)
         for (int rep = 0; rep < 2; rep++) { hipMemset(P.prof, 0, 16*8); hipEventRecord(a); hipLaunchKernelGGL(k_prof_packed, dim3((N+3)/4), dim3(64), 0, 0, P, dact); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
             long long pr[16]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
             printf("PACKED kernel %.3f ms | ticks/substep: fk %.0f low+inertia %.0f bias %.0f minv %.0f qdd+rows %.0f pgs-tail %.0f pgs-iters %.0f | per wave-step: ik %.0f loop %.0f\n", ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5]/100., pr[6]/100., (double)pr[7], (double)pr[8]); }
+    }
+    if (task == 1) { // packed one-object path: four envs per wavefront
+        hipMemcpy(P.hot, hot.data(), hot.size()*4, hipMemcpyHostToDevice); hipMemcpy(P.blocks, blk.data(), blk.size()*4, hipMemcpyHostToDevice);
+        for (int rep = 0; rep < 2; rep++) { hipMemset(P.prof, 0, 16*8); hipEventRecord(a); hipLaunchKernelGGL(k_prof_obj4, dim3((N+3)/4), dim3(64), 0, 0, P, dact); hipEventRecord(b); hipEventSynchronize(b); float ms; hipEventElapsedTime(&ms, a, b);
+            long long pr[16]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
+            printf("OBJ4 kernel %.3f ms | ticks/substep: fk %.0f detect %.0f dyn %.0f rows %.0f pgs %.0f | ik %lld loop %lld out %lld | nc %.0f con %.0f\n", ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5], pr[6], pr[7], pr[8]/100., pr[9]/100.); }
     }
     std::vector<float> h2(N*32); hipMemcpy(h2.data(), P.hot, h2.size()*4, hipMemcpyDeviceToHost); printf("q0 after: %f %f %f ee z %f\n", h2[1], h2[3], h2[5], h2[20]);
     return 0;
