@@ -493,6 +493,45 @@ def test_full_size_contact_configs_properties(built, task, N, kw):
     env.close()
 
 
+@pytest.mark.parametrize('task', ['chest_push', 'chest_pick_and_place', 'block_rearrange'])
+def test_full_size_multi_block_properties(built, task):
+    """4096 envs x 4 blocks of the tasks outside BASELINE.json's list, 12 random steps: bit-identical replay from a restored
+    state, batch-permutation equivariance, the door inside its joint limits with a 0 / 1 motor latch, goals leading with
+    the door's open state, reward consistent with the returned goals."""
+    N = 4096
+    chest = task.startswith('chest')
+    env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, num_block=4)
+    A = env.dims.action_dim
+    rs = np.random.RandomState(9)
+    env.reset()
+    for _ in range(10):
+        env.step(rs.uniform(-1, 1, (N, A)).astype(np.float32))
+    s0 = env.get_state()
+    a = rs.uniform(-1, 1, (N, A)).astype(np.float32)
+    o1, r1, d1, i1 = env.step(a)
+    s1 = env.get_state()
+    env.set_state(s0)
+    o2, r2, d2, i2 = env.step(a)
+    assert np.array_equal(o1['observation'], o2['observation']) and np.array_equal(r1, r2) and np.array_equal(s1, env.get_state())
+    perm = np.random.RandomState(8).permutation(N)
+    env.set_state(s0[perm])
+    o3, r3, _, _ = env.step(a[perm])
+    assert np.array_equal(o3['observation'], o1['observation'][perm]) and np.array_equal(r3, r1[perm])
+    assert np.isfinite(o1['observation']).all() and np.abs(o1['observation']).max() <= 5.0     # clipped (kuka_multi_step_base_env.py:306)
+    if chest:
+        upper = 0.12 if task == 'chest_push' else 0.10
+        q = o1['achieved_goal'][:, 0]
+        # (a gripper that drags the door against its stop pushes the ERP-0.2 limit row in by 0.2 mm per step: the oracle too)
+        assert (q > -5e-3).all() and (q < upper + 5e-3).all()
+        assert np.isin(s1[:, 50], [0.0, 1.0]).all() and (np.abs(upper - q[s1[:, 50] == 1.0]) < 0.02).all()
+        assert np.array_equal(o1['desired_goal'][:, 0], np.full(N, np.float32(upper)))
+        assert np.array_equal(o1['desired_goal'][:, 1:], np.tile(np.float32([-0.65, 0.0, 0.175]), (N, 4)))
+    d = np.linalg.norm(o1['achieved_goal'].astype(np.float64) - o1['desired_goal'], axis=-1)
+    clear = np.abs(d - 0.05) > 1e-4
+    assert np.array_equal(r1[clear], -(d > 0.05).astype(np.float32)[clear])
+    env.close()
+
+
 def test_batches_beyond_the_plan_kernel_fall_back_to_identity_order(built):
     """65 536 envs is what the single-workgroup plan kernel partitions; a larger batch must still step EVERY env
     (one env per wavefront, identity order)."""
