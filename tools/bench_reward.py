@@ -11,7 +11,11 @@ import ctypes as C
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 26
 G = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-env = pmg.make_env(task='reach', num_envs=64) if G == 3 else pmg.make_env(task='block_stack', num_block=G // 3, num_envs=64)
+_lib = None
+if os.environ.get('PMG_BENCH_LIB'):   # kernel A/B: an alternative build of the library
+    from pybullet_multigoal_gym_amd._lib import PmgLibrary
+    _lib = PmgLibrary(os.environ['PMG_BENCH_LIB'])
+env = pmg.make_env(task='reach', num_envs=64, _library=_lib) if G == 3 else pmg.make_env(task='block_stack', num_block=G // 3, num_envs=64, _library=_lib)
 h = env.handle
 ag, dg = h.device_alloc(B * 4 * G), h.device_alloc(B * 4 * G)
 r, ok = h.device_alloc(B * 4), h.device_alloc(B)
