@@ -2137,6 +2137,10 @@ static void chest_goal(const pmgo_env* e, const World* w, double* dg)
 
 static void env_reset_one(const pmgo_env* e, World* w)
 {
+    /* the reference's constructor resets the robot once on its own (base_env.py:42) before its first env.reset()
+     * (base_env.py:84): the very first reset of a world therefore runs the reset IK twice, each from the previous
+     * solution (kuka.py:159-160) -- pinned by tests/golden/ref_*.json */
+    if (w->reset_count == 0) robot_reset(e, w);
     robot_reset(e, w);
     if (e->multi) task_reset_multi(e, w);
     else task_reset_single(e, w);
@@ -2544,5 +2548,96 @@ int pmgo_curriculum_read(pmgo_env* e, int32_t* level, int32_t* goal_step, float*
             if (generated) generated[(size_t)i * nc + b] = (float)w->cur_count[b];
         }
     }
+    return PMG_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* Bullet-call-level access to ONE world (env 0)                        */
+/* ------------------------------------------------------------------ */
+/* tools/refharness runs the REFERENCE's own Python (make_env, reset, step, _get_obs, _compute_reward, curricula,
+ * sub-goals) on top of a scripted BulletClient whose physics calls land here: the orchestration is then the
+ * reference's, the physics this file's, and tests/golden/ref_*.json records what the pair produces.  The env-level
+ * entry points above (pmgo_reset / pmgo_step) must reproduce those records from the same seeds and actions -- which
+ * pins every orchestration row of SURVEY.md section 8(a) to reference code.  The physics itself (a21) stays
+ * [BULLET-PRIOR].  body: 0 = the Kuka (dof 0..8 = iiwa_joint_1..7, finger1, finger2), 1 = the chest (dof 0 = door). */
+static World* bw_world(pmgo_env* e) { return &e->w[0]; }
+
+/* resetJointState (robot_bases.py:192-199, 230-234) */
+int pmgo_bw_reset_joint(pmgo_env* e, int body, int dof, double q, double qd)
+{
+    World* w = bw_world(e);
+    if (body == 0 && dof >= 0 && dof < NJ) { w->q[dof] = (real)q; w->qd[dof] = (real)qd; return PMG_OK; }
+    if (body == 1 && dof == 0 && e->chest >= 0) { DOOR_Q(w) = (real)q; DOOR_QD(w) = (real)qd; return PMG_OK; }
+    return PMG_E_INVALID;
+}
+/* setJointMotorControl2 / Array in POSITION_CONTROL with gains 0.03 / 1.0 (kuka.py:282-301, chest.py:59-68);
+ * force 0 is robot_bases.py:236-238's disable_motor() */
+int pmgo_bw_motor(pmgo_env* e, int body, int dof, double target, double force)
+{
+    World* w = bw_world(e);
+    if (body == 0 && dof >= 0 && dof < NJ) { w->motor_target[dof] = (real)target; w->motor_maximp[dof] = (real)force * PHYSICS_DT; return PMG_OK; }
+    if (body == 1 && dof == 0 && e->chest >= 0) {
+        /* the door motor of this restatement is a latch with the fixed target door_open and 500 N (chest.py:59-68) */
+        if (force == 0) { DOOR_MOTOR(w) = 0; return PMG_OK; }
+        if (force != 500.0 || (real)target != e->door_open) return PMG_E_INVALID;
+        DOOR_MOTOR(w) = 1;
+        return PMG_OK;
+    }
+    return PMG_E_INVALID;
+}
+int pmgo_bw_joint_state(pmgo_env* e, int body, int dof, double out[2])
+{
+    const World* w = bw_world(e);
+    if (body == 0 && dof >= 0 && dof < NJ) { out[0] = w->q[dof]; out[1] = w->qd[dof]; return PMG_OK; }
+    if (body == 1 && dof == 0 && e->chest >= 0) { out[0] = DOOR_Q(w); out[1] = DOOR_QD(w); return PMG_OK; }
+    return PMG_E_INVALID;
+}
+/* getLinkState(computeLinkVelocity=1) of a robot link: COM position (= link frame origin for every link the
+ * reference queries: their inertial origins are zero), orientation xyzw, world linear and angular velocity */
+int pmgo_bw_link_state(pmgo_env* e, int link, double out[13])
+{
+    const World* w = bw_world(e);
+    if (link < 0 || link >= NL) return PMG_E_INVALID;
+    Kin k;
+    kinematics(w->q, &k);
+    real qt[4], v[3], om[3];
+    R_to_quat(k.R[link], qt);
+    point_velocity(&k, w->qd, link, k.c[link], v, om);
+    for (int a = 0; a < 3; a++) { out[a] = k.c[link][a]; out[7 + a] = v[a]; out[10 + a] = om[a]; }
+    for (int a = 0; a < 4; a++) out[3 + a] = qt[a];
+    return PMG_OK;
+}
+/* resetBasePositionAndOrientation of free body b: velocities are zeroed */
+int pmgo_bw_set_block(pmgo_env* e, int b, const double pos[3], const double quat[4])
+{
+    World* w = bw_world(e);
+    if (b < 0 || b >= e->nb) return PMG_E_INVALID;
+    Block* bl = &w->blk[b];
+    for (int a = 0; a < 3; a++) { bl->pos[a] = (real)pos[a]; bl->vel[a] = 0; bl->omg[a] = 0; }
+    for (int a = 0; a < 4; a++) bl->quat[a] = (real)quat[a];
+    return PMG_OK;
+}
+int pmgo_bw_block_state(pmgo_env* e, int b, double out[13])
+{
+    const World* w = bw_world(e);
+    if (b < 0 || b >= e->nb) return PMG_E_INVALID;
+    const Block* bl = &w->blk[b];
+    for (int a = 0; a < 3; a++) { out[a] = bl->pos[a]; out[7 + a] = bl->vel[a]; out[10 + a] = bl->omg[a]; }
+    for (int a = 0; a < 4; a++) out[3 + a] = bl->quat[a];
+    return PMG_OK;
+}
+/* calculateInverseKinematics from the current joint state (kuka.py:258-280) */
+int pmgo_bw_ik(pmgo_env* e, const double pos[3], const double quat[4], int max_iter, double thr, double q_out[9])
+{
+    const World* w = bw_world(e);
+    real t[3] = {(real)pos[0], (real)pos[1], (real)pos[2]}, tq[4] = {(real)quat[0], (real)quat[1], (real)quat[2], (real)quat[3]}, qo[NJ];
+    int it = ik_solve(w->q, t, tq, max_iter, (real)thr, qo);
+    for (int d = 0; d < NJ; d++) q_out[d] = qo[d];
+    return it;
+}
+/* stepSimulation: 20 substeps of 2 ms (base_env.py:203-220) */
+int pmgo_bw_step_simulation(pmgo_env* e)
+{
+    step_simulation(e, bw_world(e));
     return PMG_OK;
 }

@@ -66,6 +66,18 @@ int pmgo_cyl_box(const double cc[3], const double Rc[9], double rad, double hl, 
 /* gym.utils.seeding.np_random(seed) + RandomState draws (tests/golden/rng.json) */
 void pmgo_rng_probe(uint64_t seed, int n_double, double* out_double, int shuffle_n, int32_t* out_perm);
 
+
+/* ---- Bullet-call-level access to one world (env 0), used by tools/refharness to run the reference's own Python on
+ * this file's physics (see the comment in pmg_oracle.c); body 0 = robot (dof 0..8), 1 = chest (dof 0 = door) ---- */
+int pmgo_bw_reset_joint(pmgo_env* env, int body, int dof, double q, double qd);
+int pmgo_bw_motor(pmgo_env* env, int body, int dof, double target, double force);
+int pmgo_bw_joint_state(pmgo_env* env, int body, int dof, double out[2]);
+int pmgo_bw_link_state(pmgo_env* env, int bullet_link, double out[13]);   /* pos3 quat_xyzw4 lin3 ang3 */
+int pmgo_bw_set_block(pmgo_env* env, int b, const double pos[3], const double quat_xyzw[4]);
+int pmgo_bw_block_state(pmgo_env* env, int b, double out[13]);
+int pmgo_bw_ik(pmgo_env* env, const double pos[3], const double quat_xyzw[4], int max_iter, double threshold, double q_out[9]);
+int pmgo_bw_step_simulation(pmgo_env* env);
+
 #ifdef __cplusplus
 }
 #endif

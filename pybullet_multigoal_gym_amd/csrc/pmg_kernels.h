@@ -432,6 +432,13 @@ __device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned cha
         q = l < 7 ? cold[l] : (l < NJ ? FINGER_LIMIT : 0.f); /* kuka.py:158,161 */
         qd = 0.f;
         float tgt[3] = {(float)P.tip_init[0], (float)P.tip_init[1], (float)P.tip_init[2]};
+        /* the reference's constructor resets the robot once on its own (base_env.py:42) before its first env.reset()
+         * (:84): a world's very first reset runs the reset IK twice, the second from the first's solution (kuka.py:159-160;
+         * tests/golden/ref_*.json) */
+        if (hot[31] == 0.f) {
+            float q1 = ik_solve(c, q, tgt);
+            if (l < 7) q = q1;
+        }
         float qik = ik_solve(c, q, tgt);                       /* kuka.py:159 */
         if (l < 7) { q = qik; cold[l] = qik; }                /* kuka.py:160 */
         Kin k;

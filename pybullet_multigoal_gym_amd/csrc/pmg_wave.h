@@ -20,9 +20,20 @@ namespace wv {
 constexpr int LANES = 64; /* lanes that cooperate on one env */
 __device__ __forceinline__ int lane() { return (int)threadIdx.x; }
 
-/* wave-level LDS ordering: a single wavefront executes DS ops in order, the
- * fence only stops the compiler from moving them (workgroup = one wave). */
-__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+/* wave-level LDS ordering.  A workgroup is ONE wavefront and the LDS unit executes a wavefront's DS instructions in
+ * program order, so a later read sees an earlier write of any lane: all that is needed is to stop the COMPILER from
+ * moving memory operations across this point -- a wavefront-scope fence plus the (code-less) wave barrier.  No
+ * s_barrier: the callers sit in control flow that diverges by row in the packed layout, where a workgroup barrier
+ * would be undefined. */
+__device__ __forceinline__ void lds_sync()
+{
+#ifdef PMG_LDS_SYNC_BARRIER
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
 
 /* value of lane `src` (wave-uniform) in every lane */
 __device__ __forceinline__ float bcast(float v, int src)
@@ -120,35 +131,51 @@ namespace wr {
 constexpr int LANES = 16; /* lanes that cooperate on one env */
 __device__ __forceinline__ int lane() { return (int)threadIdx.x & 15; }
 __device__ __forceinline__ int row() { return (int)threadIdx.x >> 4; }
-__device__ __forceinline__ void lds_sync() { __syncthreads(); }
+__device__ __forceinline__ void lds_sync() { wv::lds_sync(); }
 
+/* lane SRC (compile time) of the caller's row in every lane of the row: ONE DPP move (row_newbcast, gfx90a+), which the
+ * compiler may fold into the consuming VALU instruction -- no LDS crossbar round trip */
+template <int SRC>
+__device__ __forceinline__ int bcast_ci(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xF, 0xF, false); }
 __device__ __forceinline__ int bcast_i(int v, int src)
 {
+#ifndef PMG_NO_NEWBCAST
+    /* the robot maths calls this from fully unrolled loops: src is a constant by the time the check is lowered */
+    if (__builtin_constant_p(src)) {
+        switch (src & 15) {
+        case 0: return bcast_ci<0>(v);   case 1: return bcast_ci<1>(v);   case 2: return bcast_ci<2>(v);   case 3: return bcast_ci<3>(v);
+        case 4: return bcast_ci<4>(v);   case 5: return bcast_ci<5>(v);   case 6: return bcast_ci<6>(v);   case 7: return bcast_ci<7>(v);
+        case 8: return bcast_ci<8>(v);   case 9: return bcast_ci<9>(v);   case 10: return bcast_ci<10>(v); case 11: return bcast_ci<11>(v);
+        case 12: return bcast_ci<12>(v); case 13: return bcast_ci<13>(v); case 14: return bcast_ci<14>(v); default: return bcast_ci<15>(v);
+        }
+    }
+#endif
     return __builtin_amdgcn_ds_bpermute((((int)threadIdx.x & 48) | src) << 2, v);
 }
 __device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(bcast_i(__float_as_int(v), src)); }
 template <int N>
 __device__ __forceinline__ void bcastn(const float* v, int src, float* out)
 {
-    const int addr = (((int)threadIdx.x & 48) | src) << 2;
 #pragma unroll
-    for (int k = 0; k < N; k++) out[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v[k])));
+    for (int k = 0; k < N; k++) out[k] = bcast(v[k], src);
 }
-/* broadcast of a COMPILE-TIME row lane to the lanes that hold DoFs (0..11 of the row), for the one value that
- * sits on the serial chain of every Gauss-Seidel visit: a quad broadcast, then the source quad rotated into the
- * other quads with bank-masked DPP moves -- 3 dependent VALU operations (~25 cycles) instead of an LDS crossbar
- * round trip (~120).  (Four v_readlane + selects measured SLOWER than ds_bpermute.)  Quad 3 is not written. */
+/* broadcast of a COMPILE-TIME row lane, for the one value that sits on the serial chain of every Gauss-Seidel visit */
 template <int SRC>
 __device__ __forceinline__ float bcast_c(float v)
 {
+#ifndef PMG_NO_NEWBCAST
+    return __int_as_float(bcast_ci<SRC>(__float_as_int(v)));
+#else
+    /* a quad broadcast, then the source quad rotated into the other quads with bank-masked DPP moves -- 3 dependent
+     * VALU operations instead of an LDS crossbar round trip.  Quad 3 is not written. */
     constexpr int d = SRC & 3, Q = SRC >> 2;
     const int q0 = __builtin_amdgcn_update_dpp(0, __float_as_int(v), d | (d << 2) | (d << 4) | (d << 6), 0xF, 0xF, false);
     int r = q0;
-    /* quad (Q + k) & 3 takes the source quad's copy through row_ror:4k; lanes 12..15 of a row hold nothing */
     if (((Q + 1) & 3) != 3) r = __builtin_amdgcn_update_dpp(r, q0, 0x124, 0xF, 1 << ((Q + 1) & 3), false);
     if (((Q + 2) & 3) != 3) r = __builtin_amdgcn_update_dpp(r, q0, 0x128, 0xF, 1 << ((Q + 2) & 3), false);
     if (((Q + 3) & 3) != 3) r = __builtin_amdgcn_update_dpp(r, q0, 0x12C, 0xF, 1 << ((Q + 3) & 3), false);
     return __int_as_float(r);
+#endif
 }
 template <int N>
 __device__ __forceinline__ float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }

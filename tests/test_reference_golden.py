@@ -1,0 +1,102 @@
+"""tests/golden/ref_*.json were produced by the REFERENCE's own Python (its real make_env / reset / step / _get_obs /
+_compute_reward / curricula / sub-goals, run by tools/gen_reference_fixtures.py on a scripted Bullet client whose physics
+calls land in the oracle).  Here the same sessions are demanded
+
+  * from the oracle's own env entry points: every orchestration row of SURVEY.md section 8(a) restated in
+    oracle/pmg_oracle.c must give what the reference's code gives, to float32 output rounding (the physics underneath is
+    shared, so any larger difference is an orchestration difference);
+  * from the product's kernels (CPU emulator here, the HIP library under -m gpu) through the un-batched host API
+    (num_envs=None: BASELINE.json configs[0]'s shapes), at the float32 bars of DESIGN.md section 5.
+
+The physics itself (row a21) is NOT pinned by these files: PyBullet is absent, the oracle restates it ([BULLET-PRIOR]).
+"""
+import os
+import re
+
+import pytest
+
+import ref_replay as R
+
+PATHS = R.fixture_paths()
+NAMES = [os.path.basename(p)[4:-5] for p in PATHS]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fixtures_exist():
+    assert len(PATHS) >= 24, 'run tools/gen_reference_fixtures.py (build container only)'
+    tasks = {R.load(p)['task'] for p in PATHS}
+    assert tasks == {'reach', 'push', 'pick_and_place', 'slide', 'block_stack', 'block_rearrange', 'chest_push', 'chest_pick_and_place'}
+
+
+@pytest.mark.parametrize('path', PATHS, ids=NAMES)
+def test_oracle_reproduces_reference_session(built, path):
+    fx = R.load(path)
+    env = R.OracleAdapter(fx)
+    R.replay(fx, env, tol_static=1.5e-7, tol_traj=1.5e-7)    # float32 rounding of O(1) values: 6e-8
+    env.close()
+    assert fx['urdf_fk_max_err'] < 1e-10      # the oracle's link kinematics vs the URDF text, checked at every getLinkState
+
+
+def test_world_parameters_the_reference_sets(built):
+    """base_env.py:203-220 as executed: gravity, contact ERP, 0.04 s / 20 substeps / 5 solver iterations -- against the
+    constants compiled into the kernels."""
+    src = open(os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc', 'pmg_device_body.inc')).read()
+
+    def const(name):
+        return float(re.search(r'constexpr \w+ %s = ([-0-9.e]+)f?;' % name, src).group(1))
+    for p in PATHS:
+        wp = R.load(p)['world_params']
+        assert wp['gravity'] == [0, 0, -const('GRAVITY')]
+        assert wp['contact_erp'] == pytest.approx(const('CONTACT_ERP'), abs=1e-7)
+        assert wp['fixedTimeStep'] == pytest.approx(const('PHYSICS_DT'), abs=1e-9)
+        assert wp['numSubSteps'] == const('SUBSTEPS') and wp['numSolverIterations'] == const('SOLVER_ITERS')
+        assert wp['fixedTimeStep'] / wp['numSubSteps'] == pytest.approx(const('DT'), abs=1e-9)
+
+
+@pytest.mark.parametrize('path', PATHS, ids=NAMES)
+def test_spaces_and_bullet_call_counts(built, emu_library, path):
+    """Shapes of the reference's spaces, TimeLimit, and how often the reference really steps the simulation."""
+    import warnings
+    import pybullet_multigoal_gym_amd as pmg
+    fx = R.load(path)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = pmg.make_env(task=fx['task'], num_envs=None, _library=emu_library, **fx['make_kwargs'])
+    assert env.action_space.shape == (fx['action_dim'],)
+    assert list(env.action_space.low) == fx['action_low'] and list(env.action_space.high) == fx['action_high']
+    assert env._max_episode_steps == fx['max_episode_steps']
+    for k, shape in fx['observation_space'].items():      # the reference's keys: state, policy_state, achieved_goal, desired_goal
+        assert list(env.observation_space.spaces[k].shape) == shape, k
+    env.close()
+    steps = sum(1 for e in fx['events'] if e['op'] == 'step')
+    assert fx['bullet_calls'].get('stepSimulation', 0) == 5 * steps            # kuka.py:223-225
+    assert fx['bullet_calls']['calculateInverseKinematics'] >= 2               # constructor: robot.reset() + env.reset()
+
+
+EMULATED = ['reach_short', 'block_stack4_curriculum']
+
+
+@pytest.mark.parametrize('name', EMULATED)
+def test_emulated_kernels_reproduce_reference_session(built, emu_library, name):
+    fx = R.load(os.path.join(ROOT, 'tests', 'golden', 'ref_%s.json' % name))
+    env = R.ProductAdapter(fx, library=emu_library)
+    R.replay(fx, env, tol_static=2e-5, tol_traj=5e-4, tol_vel=5e-3, threshold_guard=1e-3)
+    env.close()
+
+
+# float32 device vs the float64 physics under the fixtures: resets / goals / curricula / sub-goals to 2e-5 (positions of
+# a reset are IK solutions), trajectories at the bars of DESIGN.md section 5 over the first steps after each reset
+# measured (round 2): reach 2.5e-7 over whole episodes; contact tasks 4.6e-4 within six steps of a reset
+GPU_BARS = {'reach': dict(tol_traj=2e-5, tol_vel=2e-4, traj_steps=None)}
+GPU_DEFAULT = dict(tol_traj=1e-3, tol_vel=5e-3, traj_steps=6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', PATHS, ids=NAMES)
+def test_hip_reproduces_reference_session(built, hip_library, path):
+    fx = R.load(path)
+    env = R.ProductAdapter(fx, library=hip_library)
+    bars = GPU_BARS.get(fx['task'], GPU_DEFAULT)
+    worst = R.replay(fx, env, tol_static=2e-5, threshold_guard=2e-3, **bars)
+    env.close()
+    print('worst', os.path.basename(path), worst)
