@@ -40,7 +40,7 @@ struct EnvParams {
     int* sched;      /* [3 + 3N]: counts of {contact-prone, other} envs, the two env lists, then the redo count + list
                         of the row-packed path (pmg_packed.h) */
 #ifdef PMG_PROFILE
-    long long* prof; /* per-phase wall_clock64 ticks of env 0 */
+    long long* prof; /* [32] per-phase shader cycles of env 0 */
 #endif
 };
 }  // namespace pmgx
@@ -48,7 +48,7 @@ struct EnvParams {
 namespace pmg {
 
 #ifdef PMG_PROFILE
-#define PMG_TICK(i) do { long long t_ = wall_clock64(); if (wv::lane() == 0 && blockIdx.x == 0) P.prof[i] += t_ - tprev; tprev = wall_clock64(); } while (0)
+#define PMG_TICK(i) PMG_STAMP(tprev, i)
 #else
 #define PMG_TICK(i) do { } while (0)
 #endif

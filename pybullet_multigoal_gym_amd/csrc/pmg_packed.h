@@ -19,8 +19,8 @@
 namespace pmgp {
 
 #ifdef PMG_PROFILE
-#define PMGP_T0() long long pt_ = wall_clock64()
-#define PMGP_T(i) do { long long n_ = wall_clock64(); if (threadIdx.x == 0 && blockIdx.x == 0 && P.prof) P.prof[i] += n_ - pt_; pt_ = wall_clock64(); } while (0)
+#define PMGP_T0() long long pt_ = prof::now()
+#define PMGP_T(i) PMG_STAMP(pt_, i)
 #else
 #define PMGP_T0() do { } while (0)
 #define PMGP_T(i) do { } while (0)
@@ -59,11 +59,9 @@ __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
     PMGP_T(4);
     float dv = 0.f;
-    for (int it = 0; it < SOLVER_ITERS; it++) {
-        nc_sweep(r, (it & 1) != 0, minv, dv);
-        if (wr::max_row0(nc_residual(r)) <= RESIDUAL_THRESHOLD) break;
-        PMGP_T(6);
-    }
+    McState mc;
+    mc_init(r, minv, mc);
+    nc_solve_free(r, mc, minv, dv);
     PMGP_T(5);
     if (l < NJ) qd += dv;
     q += DT * qd;
@@ -114,6 +112,9 @@ __device__ __forceinline__ void step_group(const EnvParams& P, const float* acti
     const int idx = 4 * group + wr::row();
     const bool have = idx < n1;                        /* surplus rows of the last wave shadow its last env and write nothing */
     const int env = P.sched[2 + P.n_envs + (have ? idx : n1 - 1)];
+#ifdef PMG_PROFILE
+    prof::begin();
+#endif
     LaneConst c;
     load_lane_const(lcs, c);
     float* hot = P.hot + (size_t)env * HOT_DIM;
@@ -146,6 +147,9 @@ __device__ __forceinline__ void step_group(const EnvParams& P, const float* acti
         for (int ss = 0; ss < SUBSTEPS && ok; ss++) ok = substep_free(P, c, q, qd, tau, mtarget, mimp);
     }
     PMGP_T(8);
+#ifdef PMG_PROFILE
+    prof::flush(P.prof);
+#endif
     if (!have) return;
     if (!ok) {                                         /* mispredicted: leave the state untouched, queue the env for pmg_k_redo */
         if (l == 0) {

@@ -51,6 +51,16 @@ __device__ __forceinline__ void bcastn(const float* v, int src, float* out)
 #pragma unroll
     for (int k = 0; k < N; k++) out[k] = bcast(v[k], src);
 }
+/* acc1 += c1 * v[lane SRC], acc2 += c2 * v[lane SRC]: the tail of a Gauss-Seidel visit (one v_readlane, two fmas) */
+template <int SRC>
+__device__ __forceinline__ void fma2_bcast_c(float v, float c1, float& acc1, float c2, float& acc2)
+{
+    const float b = bcast_c<SRC>(v);
+    acc1 = fmaf(c1, b, acc1);
+    acc2 = fmaf(c2, b, acc2);
+}
+/* does p hold in any lane of the env?  (wave-uniform here) */
+__device__ __forceinline__ bool any_lane(bool p) { return __ballot(p) != 0ull; }
 
 template <int CTRL>
 __device__ __forceinline__ float dpp(float old, float v)
@@ -114,6 +124,8 @@ __device__ __forceinline__ float max_all(float v)
     return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
 }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+/* lanes 0..15 of the env(s) of this wavefront where p holds, wave-uniform: here one env = the whole wave */
+__device__ __forceinline__ unsigned any_row_mask(bool p) { return (unsigned)(__ballot(p) & 0xFFFFull); }
 /* v holds the same value in every lane: test v > 0 on the scalar unit (one v_readfirstlane) */
 __device__ __forceinline__ bool uniform_positive(float v) { return __builtin_amdgcn_readfirstlane(__float_as_int(v)) > 0; }
 /* optimisation barrier on a per-lane index: everything loaded through it is re-loaded */
@@ -136,7 +148,7 @@ __device__ __forceinline__ void lds_sync() { wv::lds_sync(); }
 /* lane SRC (compile time) of the caller's row in every lane of the row: ONE DPP move (row_newbcast, gfx90a+), which the
  * compiler may fold into the consuming VALU instruction -- no LDS crossbar round trip */
 template <int SRC>
-__device__ __forceinline__ int bcast_ci(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xF, 0xF, false); }
+__device__ __forceinline__ int bcast_ci(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + SRC, 0xF, 0xF, true); }
 __device__ __forceinline__ int bcast_i(int v, int src)
 {
 #ifndef PMG_NO_NEWBCAST
@@ -177,6 +189,26 @@ __device__ __forceinline__ float bcast_c(float v)
     return __int_as_float(r);
 #endif
 }
+/* acc1 += c1 * v[row lane SRC], acc2 += c2 * v[row lane SRC]: the broadcast rides on the DPP operand of the two
+ * multiply-adds (v_fmac_f32_dpp; the compiler does not fold row_newbcast itself).  The s_nop covers the two wait states
+ * a DPP read needs after the VALU write of v, which the compiler cannot see through the asm. */
+template <int SRC>
+__device__ __forceinline__ void fma2_bcast_c(float v, float c1, float& acc1, float c2, float& acc2)
+{
+#if !defined(PMG_NO_NEWBCAST) && !defined(PMG_NO_DPP_FMAC)
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc1), "+v"(acc2)
+                 : "v"(v), "v"(c1), "v"(c2), "n"(SRC));
+#else
+    const float b = bcast_c<SRC>(v);
+    acc1 = fmaf(c1, b, acc1);
+    acc2 = fmaf(c2, b, acc2);
+#endif
+}
+/* does p hold in any lane of the caller's env (= row)?  Per lane, diverges by row */
+__device__ __forceinline__ bool any_lane(bool p) { return ((__ballot(p) >> ((int)threadIdx.x & 48)) & 0xFFFFull) != 0ull; }
 template <int N>
 __device__ __forceinline__ float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }
 template <int N>
@@ -195,6 +227,12 @@ __device__ __forceinline__ float max_all(float v) { return wv::row_max(v); }
 __device__ __forceinline__ bool uniform_positive(float v) { return v > 0.f; }
 /* predicate mask of the caller's row (bit i = row lane i) */
 __device__ __forceinline__ unsigned long long ballot(bool p) { return (__ballot(p) >> ((int)threadIdx.x & 48)) & 0xFFFFull; }
+/* row lanes where p holds in ANY of the four envs of the wavefront: wave-uniform (a scalar), unlike ballot() */
+__device__ __forceinline__ unsigned any_row_mask(bool p)
+{
+    const unsigned long long b = __ballot(p);
+    return (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xFFFFull);
+}
 __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
 
 }  // namespace wr

@@ -130,6 +130,15 @@ inline unsigned long long ballot(bool p)
     exchange_done();
     return m;
 }
+inline unsigned any_row_mask(bool p) { return (unsigned)(ballot(p) & 0xFFFFull); }
+inline bool any_lane(bool p) { return ballot(p) != 0ull; }
+template <int SRC>
+inline void fma2_bcast_c(float v, float c1, float& acc1, float c2, float& acc2)
+{
+    const float b = bcast(v, SRC);
+    acc1 = fmaf(c1, b, acc1);
+    acc2 = fmaf(c2, b, acc2);
+}
 }  // namespace wv
 
 /* row-packed variant (four envs per wave, one per 16-lane row): see the product header.  The fiber scheduler
@@ -184,5 +193,16 @@ inline unsigned long long ballot(bool p)
     return m;
 }
 inline void opaque(int& i) { (void)i; }
+/* the device ORs the four rows (a wave-uniform mask that only decides which rows get a -- possibly empty -- visit);
+ * rows of the emulator may have diverged, so each row answers for itself: same results, fewer empty visits */
+inline unsigned any_row_mask(bool p) { return (unsigned)ballot(p); }
+inline bool any_lane(bool p) { return ballot(p) != 0ull; }
+template <int SRC>
+inline void fma2_bcast_c(float v, float c1, float& acc1, float c2, float& acc2)
+{
+    const float b = bcast(v, SRC);
+    acc1 = fmaf(c1, b, acc1);
+    acc2 = fmaf(c2, b, acc2);
+}
 }  // namespace wr
 #endif

@@ -27,7 +27,8 @@ def test_device_dynamics_functions_match_oracle(emu_library):
         lib.pmge_probe_dynamics(_fp(q), _fp(qd), _fp(tau), _fp(qdd), _fp(mi), _fp(tip))
         ref = O.fdyn(q.astype(float), qd.astype(float), tau.astype(float))
         assert np.abs(qdd - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
-        assert np.abs(mi.reshape(9, 9) - O.minv(q.astype(float))).max() < 5e-5
+        mref = O.minv(q.astype(float))
+        assert np.abs(mi.reshape(9, 9) - mref).max() < 1e-5 * np.abs(mref).max()    # float32 Gauss-Jordan, cond(M) ~ 1e3
         p, R = O.fk_tip(q.astype(float))
         assert np.abs(tip[:3] - p).max() < 1e-6 and np.abs(tip[3:].reshape(3, 3) - R).max() < 1e-6
 
