@@ -1,24 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the batched Kuka env on N MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          # N > 1: spawns one rank per GPU itself
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or is launched per rank
 
-One "step" = one batched env.step() over 4096 envs per GPU (BASELINE.json
-configs[1]: task='reach', 4096 vectorised envs, random policy, state obs),
-actions pre-generated and resident in HBM, episodes reset every
-max_episode_steps=50 steps inside the timed region, and -- for N > 1 -- one RCCL
-all-gather of the packed observation shard per step.  Rank 0 prints ONE JSON line.
+One "step" = one batched env.step() over 4096 envs per GPU (BASELINE.json configs[1]: task='reach', 4096 vectorised
+envs, random policy, state obs), actions pre-generated and resident in HBM, episodes reset every max_episode_steps=50
+steps inside the timed region, and -- for N > 1 -- one RCCL all-gather of the packed observation shard per step.  W
+untimed warm-up steps, then EXACTLY K timed steps between barrier + stream sync; the slowest rank's time counts; rank 0
+prints ONE JSON line.  `value` is that K-step window; because a short window early in an episode flatters the number
+(no env has walked down to the table yet), the line also says which episode steps the window covered and carries
+`full_episodes` (the same loop over whole episodes) and `host_api` (numpy in / numpy out through env.step(), PCIe
+inclusive) as secondary fields -- never as `value`.
 
-The env is the C-ABI HIP library (ctypes); the synthetic action table is
-uploaded once into a device buffer it owns.  torch is imported only for the
-torch.distributed (gloo) rendezvous / barrier of multi-GPU runs -- it never
-creates a HIP context here (its wheel bundles a different HIP runtime than
-/opt/rocm).
+The env is the C-ABI HIP library (ctypes).  No PyTorch anywhere: the ranks rendezvous over stdlib TCP
+(pybullet_multigoal_gym_amd.distributed.Rendezvous) for the 128-byte RCCL id, the barriers and the max over ranks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,35 +35,40 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 ALGO_BYTES = {'reach': 298, 'push': 486, 'slide': 486, 'pick_and_place': 490, 'block_stack': 1246, 'block_rearrange': 1242,
               # chest tasks with 4 blocks: state (24 + 4*13 + 3 door floats, order, counter + RNG cursor) r+w 704, action, outputs 618
               'chest_push': 1334, 'chest_pick_and_place': 1338}
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+# MI355X_MICROARCH.md "Wave scheduling": 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
+VALU_PEAK_INSTS = 1024 * 2.4e9 / 2          # 1.2288e12 wave-instructions / s
+FP32_PEAK_TFLOPS = 157.3                    # 256 CU x 4 SIMD x 32 lanes x 2 flop x 2.4 GHz (vector fp32, = the fp32 MFMA rate)
+
+
+def _committed(pattern):
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), reverse=True)   # newest round tag first
 
 
 def committed_traffic(task, n_envs):
-    """HBM bytes per pmg_k_step launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, KiB -> bytes; the
-    guide's x2 FETCH correction applies to 16 B/lane streaming reads only -- these are dword accesses, so
-    the raw counters are reported).  None when no pass is committed for this workload."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+    """HBM bytes per batched step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command, KiB -> bytes, with the calibration factors of the
+    same file applied -- MI355X_MICROARCH.md: calibrate on a known byte count in your own access pattern).  None when no
+    pass is committed for this workload."""
+    for f in _committed('*_%s%d_pmc_traffic.json' % (task, n_envs)):
         try:
             d = json.load(open(f))
-        except Exception:
-            continue
-        if d.get('task') == task and d.get('envs_per_gpu') == n_envs:
-            best = d
-    return None if best is None else float(best['hbm_bytes_per_launch'])
-
-
-def committed_valu(task, n_envs):
-    """SQ_INSTS_VALU per pmg_k_step launch from the committed PMC pass (profiles/*_pmc_summary.json), or None."""
-    import glob
-    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s%d_pmc_summary.json' % (task, n_envs))), reverse=True):
-        try:
-            return float(json.load(open(f))['SQ_INSTS_VALU']['mean_per_launch'])
+            if d.get('task') == task and d.get('envs_per_gpu') == n_envs:
+                return float(d['hbm_bytes_per_launch'])
         except Exception:
             continue
     return None
+
+
+def committed_counters(task, n_envs):
+    """Per-step instruction counters of the committed PMC pass (profiles/*_pmc_summary.json), or {}."""
+    for f in _committed('*_%s%d_pmc_summary.json' % (task, n_envs)):
+        try:
+            return {k: float(v['mean_per_launch']) for k, v in json.load(open(f)).items()}
+        except Exception:
+            continue
+    return {}
 
 
 def usable_cores():
@@ -77,9 +84,8 @@ def usable_cores():
 
 
 def cpu_baseline(task, budget_s=12.0):
-    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a
-    bounded sample of the same workload: 64 envs per core, random actions, until
-    ~budget_s of wall time has passed (at least 3 batched steps)."""
+    """The oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded sample of the same
+    workload: 64 envs per core, random actions, until ~budget_s of wall time has passed (at least 3 batched steps)."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import oracle_lib
     cores = usable_cores()
@@ -99,7 +105,28 @@ def cpu_baseline(task, budget_s=12.0):
     ora.close()
     return {'value': n * steps / el, 'unit': 'env-steps/s', 'cores': cores, 'kind': 'port',
             'sample': '%d envs x %d steps of task=%s on %d OpenMP threads (oracle/pmg_oracle.c, float64); '
-                      'PyBullet itself is absent on this box' % (n, steps, task, cores)}
+                      'PyBullet itself is absent on this box, so this is NOT the reference and no speed-up over the '
+                      'reference may be read off it' % (n, steps, task, cores)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE in the env,
+    a free TCP port for the rendezvous) and pass rank 0's line through."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   PMG_RDV_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -110,99 +137,111 @@ def main():
     ap.add_argument('--task', default='reach')
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary full_episodes / host_api measurements')
     ap.add_argument('--episode-steps', type=int, default=50)
     ap.add_argument('--dense-reward', action='store_true', help='binary_reward=False (BASELINE.json configs[3] runs both)')
     ap.add_argument('--lib', default=None, help='alternative libpmg_hip.so build (kernel A/B experiments)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+
     import pybullet_multigoal_gym_amd as pmg
+    from pybullet_multigoal_gym_amd._lib import PmgLibrary
+    from pybullet_multigoal_gym_amd.distributed import Rendezvous, init_rccl
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    # PMG_BENCH_FORCE_DIST=1 takes the multi-rank code path (torch.distributed rendezvous, RCCL communicator,
-    # per-step all-gather) even with one rank: lets a 1-GPU box validate what the N > 1 launch will execute
+    if world != args.gpus:
+        sys.exit('bench.py: WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    # PMG_BENCH_FORCE_DIST=1 takes the multi-rank code path (rendezvous, RCCL communicator, per-step all-gather) even
+    # with one rank: lets a 1-GPU box validate what the N > 1 launch will execute
     multi = world > 1 or bool(os.environ.get('PMG_BENCH_FORCE_DIST'))
-    if multi:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('gloo')  # rendezvous + barrier only; the data path is RCCL inside the library
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    rdv = Rendezvous(rank, world) if multi else None
 
     N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, args.episode_steps
-    from pybullet_multigoal_gym_amd._lib import PmgLibrary
     env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=local_rank, seed=0, seed_stride=1,
                        env_index_offset=rank * N, max_episode_steps=T, binary_reward=not args.dense_reward,
                        _library=PmgLibrary(args.lib) if args.lib else None)
     h = env.handle
     A = env.dims.action_dim
     gathered = None
-    host_gather = None
-    collective = 'RCCL all-gather of packed obs'
+    host_gather = False
+    collective = 'none (one rank: nothing to gather)'
     if multi:
-        uid = [h.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        try:
-            if os.environ.get('PMG_BENCH_FORCE_COMM_FAIL'):   # test hook for the fallback below
-                raise RuntimeError('forced by PMG_BENCH_FORCE_COMM_FAIL')
-            h.comm_init(rank, world, uid[0])
-            ok = 1
-        except Exception as ex:   # noqa: BLE001 -- reported below, never silent
-            print('rank %d: RCCL communicator failed (%s)' % (rank, ex), file=sys.stderr, flush=True)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
+        # PMG_BENCH_FORCE_COMM_FAIL: test hook for the fallback below
+        if init_rccl(env, rdv, _force_fail=bool(os.environ.get('PMG_BENCH_FORCE_COMM_FAIL'))):
             gathered = h.device_alloc(world * N * env.dims.packed_dim * 4)
+            collective = 'one RCCL all-gather of the packed obs rows per step (%d B per rank)' % (N * env.dims.packed_dim * 4)
         else:
-            # every rank takes the SAME fallback, and the JSON line says so: packed rows to the host, gloo all-gather
-            collective = 'FALLBACK: RCCL init failed, host gloo all-gather of packed obs (PCIe-inclusive)'
-            mine = torch.empty((N, env.dims.packed_dim), dtype=torch.float32)
-            host_gather = (mine, [torch.empty_like(mine) for _ in range(world)])
-    # synthetic random policy: a table of K+W batches of U(-1,1) float32 actions, resident in HBM
-    table = np.random.RandomState(12345 + rank).uniform(-1, 1, (K + W, N, A)).astype(np.float32)
+            # every rank takes the SAME fallback, and the JSON line says so: packed rows to the host, TCP all-gather
+            collective = 'FALLBACK: RCCL init failed, host all-gather of packed obs (PCIe + TCP inclusive)'
+            host_gather = True
+    # synthetic random policy: a table of batches of U(-1,1) float32 actions, resident in HBM
+    E = 0 if args.no_extras else 2 * T                     # extra whole episodes for the secondary measurement
+    table = np.random.RandomState(12345 + rank).uniform(-1, 1, (K + W + E, N, A)).astype(np.float32)
     actions = h.device_alloc(table.nbytes)
     h.upload(actions, table)
     stride = N * A * 4
+    mine = np.empty((N, env.dims.packed_dim), np.float32) if host_gather else None
 
-    def run(first, count):
+    def run(first, count, phase0=0):
         for t in range(first, first + count):
-            if t % T == 0:
+            if (t - phase0) % T == 0:
                 h.reset_device(None)
             h.step_device(actions + t * stride)
             if gathered is not None:
                 h.allgather_packed(gathered)
-            elif host_gather is not None:
+            elif host_gather:
                 h.sync()
-                h.download(host_gather[0].numpy(), h.device_ptr())
-                dist.all_gather(host_gather[1], host_gather[0])
+                h.download(mine, h.device_ptr())
+                rdv.allgather(mine)
 
     def fence():
         h.sync()                       # the library's stream: every kernel and the all-gather
-        if 'torch' in sys.modules and sys.modules['torch'].cuda.is_initialized():
-            sys.modules['torch'].cuda.synchronize()
         if multi:
-            dist.barrier()
+            rdv.barrier()
+
+    def timed(first, count, phase0=0):
+        fence()
+        h.timing_reset()
+        t0 = time.perf_counter()
+        run(first, count, phase0)
+        fence()
+        el = time.perf_counter() - t0
+        return rdv.max(el) if multi else el
 
     run(0, W)
-    fence()
-    h.timing_reset()
-    t0 = time.perf_counter()
-    run(W, K)
-    fence()
-    el = time.perf_counter() - t0
-    if multi:
-        tt = torch.tensor([el], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)   # slowest rank
-        el = float(tt[0])
-    kernel_ms, launches = h.timing_read()
+    el = timed(W, K)
+    kmin, kernel_ms, kmax, launches = h.timing_stats()
+    full = None
+    if E:
+        el_full = timed(K + W, E, phase0=K + W)            # starts with a reset: exactly two whole episodes
+        fmin, favg, fmax, fl = h.timing_stats()
+        full = {'value': world * N * E / el_full, 'unit': 'env-steps/s', 'steps': E, 'ms_per_step': el_full / E * 1e3,
+                'kernel_ms': {'min': fmin, 'avg': favg, 'max': fmax},
+                'note': 'the same loop over %d whole %d-step episodes (every episode phase weighted equally)' % (E // T, T)}
+    host = None
+    if E and world == 1:
+        # what a numpy-only RL loop gets: env.step(numpy actions) -> numpy observations (H2D actions, kernel, D2H packed
+        # rows, unpack); one whole episode.  Never `value`.
+        hs = T
+        acts = table[:hs]
+        env.reset()
+        t0 = time.perf_counter()
+        for t in range(hs):
+            env.step(acts[t])
+        elh = time.perf_counter() - t0
+        host = {'value': N * hs / elh, 'unit': 'env-steps/s', 'steps': hs, 'ms_per_step': elh / hs * 1e3,
+                'bytes_h2d_per_step': N * A * 4, 'bytes_d2h_per_step': N * env.dims.packed_dim * 4,
+                'path': 'env.step(numpy [N,A]) -> dict of numpy arrays, reward, done, info (PCIe inclusive)'}
 
     if rank == 0:
         value = world * N * K / el
         algo = ALGO_BYTES[args.task] * N
         achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        first_ep = W % T
         out = {
             'metric': 'env-steps/sec at N_envs=4096/GPU, KukaReach' if args.task == 'reach' and N == 4096
                       else 'env-steps/sec at N_envs=%d/GPU, %s' % (N, args.task),
@@ -212,31 +251,50 @@ def main():
             'config': {'workload': "task='%s', %d vectorised envs/GPU, random policy U(-1,1), state obs, %s reward, "
                                    'reset every %d steps, 100 substeps/env-step'
                                    % (args.task, N, 'dense' if args.dense_reward else 'binary', T),
-                       'global_envs': world * N, 'parallelism': 'env-shard x%d, %s' % (world, collective)},
+                       'global_envs': world * N, 'parallelism': 'env-shard x%d; %s' % (world, collective),
+                       'window': 'timed steps = episode steps %d..%d of %d-step episodes%s' % (
+                           first_ep, first_ep + K - 1, T, '' if K >= T else
+                           ' (shorter than an episode: see full_episodes for the phase-weighted rate)')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': committed_traffic(args.task, N),
-                         'kernel': 'pmg_k_step_reach (+ pmg_k_redo)' if args.task == 'reach' else 'pmg_k_step<NB,MAXC,CYL>', 'kernel_ms': kernel_ms, 'launches': launches,
+                         'kernel': 'pmg_k_step_reach (+ pmg_k_redo)' if args.task == 'reach' else 'pmg_k_step<NB,MAXC,CYL> family',
+                         'kernel_ms': kernel_ms, 'kernel_ms_min': kmin, 'kernel_ms_max': kmax, 'launches': launches,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES[args.task],
-                         'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by '
-                                 'construction (SURVEY.md 8d); the binding resource is the dependency latency of that chain '
-                                 '(slowest wavefront = envs with finger-table contacts) and VALU issue, see roofline.valu'},
+                         'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by construction '
+                                 '(SURVEY.md 8d).  What binds it is the dependent-issue latency of that chain (one wavefront '
+                                 'issues ~1 instruction / 4.3 cycles; a batched step lasts as long as its slowest wavefront = '
+                                 'an env with finger-table contacts: kernel_ms_max vs kernel_ms_min); see roofline.valu'},
         }
-        vi = committed_valu(args.task, N)
-        if vi is not None and kernel_ms > 0:
-            # the resource that actually binds this path: wave64 VALU issue, 1 instruction / 4 cycles / SIMD,
-            # 1024 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
-            out['roofline']['valu'] = {'insts_per_launch': vi, 'peak_insts_per_s': 1024 * 2.4e9 / 4,
-                                       'util': vi / (kernel_ms * 1e-3) / (1024 * 2.4e9 / 4),
-                                       'source': 'SQ_INSTS_VALU of the committed rocprofv3 --pmc pass over the live kernel time'}
+        cnt = committed_counters(args.task, N)
+        if cnt.get('SQ_INSTS_VALU') and kernel_ms > 0:
+            vi = cnt['SQ_INSTS_VALU']
+            v = {'insts_per_launch': vi, 'peak_insts_per_s': VALU_PEAK_INSTS, 'util': vi / (kernel_ms * 1e-3) / VALU_PEAK_INSTS,
+                 'source': 'SQ_INSTS_VALU of the committed rocprofv3 --pmc pass over the live kernel time; peak = 1024 SIMD-32 '
+                           'x 2.4 GHz / 2 cycles per wave64 instruction'}
+            fl = [cnt.get('SQ_INSTS_VALU_ADD_F32'), cnt.get('SQ_INSTS_VALU_MUL_F32'), cnt.get('SQ_INSTS_VALU_FMA_F32'), cnt.get('SQ_INSTS_VALU_TRANS_F32')]
+            if all(x is not None for x in fl):
+                flops = 64.0 * (fl[0] + fl[1] + 2.0 * fl[2] + fl[3])      # per launch, 64 lanes per wave instruction
+                v.update(fp32_flop_per_launch=flops, achieved_tflops=flops / (kernel_ms * 1e-3) / 1e12, peak_tflops=FP32_PEAK_TFLOPS,
+                         flop_frac=flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         flop_source='64 x (ADD_F32 + MUL_F32 + 2 FMA_F32 + TRANS_F32) wave-instruction counters: an upper bound, idle lanes included')
+            out['roofline']['valu'] = v
+        if full is not None:
+            out['full_episodes'] = full
+        if host is not None:
+            out['host_api'] = host
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.task)
         print(json.dumps(out), flush=True)
+    if os.environ.get('PMG_ASSERT_NO_TORCH') and rank == 0:   # test hook: the ranks run without PyTorch
+        assert 'torch' not in sys.modules, 'torch was imported by a bench rank'
+        print('no torch in rank 0 (%d modules loaded)' % len(sys.modules), file=sys.stderr, flush=True)
     h.device_free(actions)
     if gathered is not None:
         h.device_free(gathered)
     env.close()
-    if multi:
-        dist.destroy_process_group()
+    if rdv is not None:
+        rdv.barrier()
+        rdv.close()
 
 
 if __name__ == '__main__':

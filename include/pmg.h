@@ -120,7 +120,9 @@ int pmg_seed(pmg_env* env, uint64_t seed_base, uint64_t seed_stride);
  * (kuka.py:120-165) + _task_reset/_generate_goal (kuka_single_step_base_env.py:76-148;
  * kuka_multi_step_base_env.py:183-250; kuka_multi_step_envs.py:34-87) + _get_obs.
  * mask: N bytes (nonzero = reset this env) or NULL = all.  Output pointers may
- * be NULL to skip the copy-out. */
+ * be NULL to skip the copy-out.  Envs outside the mask keep their state; their rows of PMG_BUF_PACKED get a fresh
+ * observation / desired goal of that state and KEEP reward | goal_achieved | done of their last step (a device-resident
+ * loop may step, reset(mask = done) and then still read every env's last reward). */
 int pmg_reset(pmg_env* env, const uint8_t* mask, float* observation, float* policy_state,
               float* achieved_goal, float* desired_goal);
 
@@ -153,7 +155,7 @@ int pmg_compute_reward_device(pmg_env* env, const float* d_achieved_goal, const 
  * state: [N, state_dim] float32, layout documented in DESIGN.md (with use_curriculum the row ends with 16
  * floats of curriculum state: prob[5] generated[5] goal_step; chest tasks prob[6] generated[6] goal_step). */
 int pmg_get_state(pmg_env* env, float* state);
-int pmg_set_state(pmg_env* env, const float* state);
+int pmg_set_state(pmg_env* env, const float* state);   /* also refreshes the observation part of PMG_BUF_PACKED */
 /* Host-injected goal / object poses for seed-parity tests (replaces the RNG
  * draws of _generate_goal for the masked envs).  goals: [N, goal_dim].  PMG_E_INVALID for the chest tasks (their goal
  * is the chest: no static target; goal row [0..2] holds the door joint position, velocity and motor latch). */
@@ -197,6 +199,15 @@ int pmg_download(pmg_env* env, void* h_dst, const void* d_src, uint64_t bytes); 
  * over the launches since the last pmg_timing_reset(). */
 int pmg_timing_reset(pmg_env* env);
 int pmg_timing_read(pmg_env* env, double* avg_step_kernel_ms, int64_t* launches);
+/* the same launches: shortest / average / longest (any pointer may be NULL).  A batched step lasts as long as its slowest
+ * wavefront, so the spread shows how often envs with finger x table / object contacts were in the batch. */
+int pmg_timing_stats(pmg_env* env, double* min_ms, double* avg_ms, double* max_ms, int64_t* launches);
+
+/* The per-env MT19937 streams (625 words each: state + cursor), [N, 625] uint32: with pmg_get_state / pmg_set_state a
+ * checkpoint that resumes with the SAME future goals, orders and curriculum draws (no reference equivalent).  The
+ * curriculum-update switch is host state: restore it with pmg_curriculum_update. */
+int pmg_get_rng(pmg_env* env, uint32_t* words);
+int pmg_set_rng(pmg_env* env, const uint32_t* words);
 
 #ifdef __cplusplus
 }

@@ -49,7 +49,7 @@ class PmgLibrary:
                'pmg_compute_reward', 'pmg_compute_reward_device', 'pmg_get_state', 'pmg_set_state', 'pmg_set_goal',
                'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_read',
                'pmg_device_alloc', 'pmg_device_free', 'pmg_upload', 'pmg_download',
-               'pmg_set_sub_goal', 'pmg_curriculum_update', 'pmg_curriculum_read']
+               'pmg_set_sub_goal', 'pmg_curriculum_update', 'pmg_curriculum_read', 'pmg_timing_stats', 'pmg_get_rng', 'pmg_set_rng']
 
     def __init__(self, path=None):
         self.path = path or DEFAULT_LIBRARY
@@ -244,6 +244,24 @@ class PmgHandle:
         n = C.c_int64()
         self._check(self.L.lib.pmg_timing_read(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def timing_stats(self):
+        """(min, avg, max) ms of the step-kernel launches since timing_reset(), and their count."""
+        lo, avg, hi = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int64()
+        self._check(self.L.lib.pmg_timing_stats(self.h, C.byref(lo), C.byref(avg), C.byref(hi), C.byref(n)))
+        return lo.value, avg.value, hi.value, n.value
+
+    def get_rng(self):
+        w = np.empty((self.N, 625), np.uint32)
+        self._check(self.L.lib.pmg_get_rng(self.h, _p(w)))
+        return w
+
+    def set_rng(self, words):
+        w = np.ascontiguousarray(words, np.uint32)
+        if w.shape != (self.N, 625):
+            raise ValueError('rng words must have shape (%d, 625)' % self.N)
+        self._check(self.L.lib.pmg_set_rng(self.h, _p(w)))
 
     def comm_unique_id(self):
         buf = (C.c_uint8 * 128)()

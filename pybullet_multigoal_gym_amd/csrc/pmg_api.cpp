@@ -110,7 +110,7 @@ struct pmg_env {
     long long rw_cap = 0;
     hipEvent_t ev_a[EVENT_POOL], ev_b[EVENT_POOL];
     int ev_n = 0;
-    double ev_ms = 0.0;
+    double ev_ms = 0.0, ev_min = 0.0, ev_max = 0.0;
     long long ev_launches = 0;
     bool ever_reset = false;
     int packed = 1;                   /* reach: contact-free envs four per wavefront (PMG_PACKED=0 switches it off) */
@@ -273,7 +273,11 @@ void drain_events(pmg_env* e)
     for (int i = 0; i < e->ev_n; i++) {
         float ms = 0.f;
         (void)hipEventSynchronize(e->ev_b[i]);
-        if (hipEventElapsedTime(&ms, e->ev_a[i], e->ev_b[i]) == hipSuccess) { e->ev_ms += ms; e->ev_launches++; }
+        if (hipEventElapsedTime(&ms, e->ev_a[i], e->ev_b[i]) == hipSuccess) {
+            if (e->ev_launches == 0 || ms < e->ev_min) e->ev_min = ms;
+            if (e->ev_launches == 0 || ms > e->ev_max) e->ev_max = ms;
+            e->ev_ms += ms; e->ev_launches++;
+        }
     }
     e->ev_n = 0;
 }
@@ -575,6 +579,29 @@ int pmg_set_state(pmg_env* e, const float* state)
         HIP_TRY(e, hipMemcpy(e->P.curr, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     e->ever_reset = true;
+    /* the packed rows still show the previous state: a reset of NOBODY re-derives every env's observation and goal */
+    HIP_TRY(e, hipMemsetAsync(e->d_mask, 0, N, e->stream));
+    HIP_TRY(e, pmg_launch_reset(e->P, e->d_mask, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return PMG_OK;
+}
+
+int pmg_get_rng(pmg_env* e, uint32_t* words)
+{
+    if (!e || !words) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(words, e->P.rng, (size_t)e->dims.num_envs * 625 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return PMG_OK;
+}
+int pmg_set_rng(pmg_env* e, const uint32_t* words)
+{
+    if (!e || !words) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (int i = 0; i < e->dims.num_envs; i++)
+        if (words[(size_t)i * 625 + 624] > 624u) return fail(e, PMG_E_INVALID, "pmg_set_rng: env %d has cursor %u > 624", i, words[(size_t)i * 625 + 624]);
+    HIP_TRY(e, hipMemcpy(e->P.rng, words, (size_t)e->dims.num_envs * 625 * sizeof(uint32_t), hipMemcpyHostToDevice));
     return PMG_OK;
 }
 
@@ -712,8 +739,20 @@ int pmg_timing_reset(pmg_env* e)
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->ev_n = 0;
-    e->ev_ms = 0.0;
+    e->ev_ms = e->ev_min = e->ev_max = 0.0;
     e->ev_launches = 0;
+    return PMG_OK;
+}
+int pmg_timing_stats(pmg_env* e, double* min_ms, double* avg_ms, double* max_ms, int64_t* launches)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    drain_events(e);
+    if (min_ms) *min_ms = e->ev_min;
+    if (max_ms) *max_ms = e->ev_max;
+    if (avg_ms) *avg_ms = e->ev_launches ? e->ev_ms / (double)e->ev_launches : 0.0;
+    if (launches) *launches = e->ev_launches;
     return PMG_OK;
 }
 int pmg_timing_read(pmg_env* e, double* avg_ms, int64_t* launches)

@@ -459,7 +459,7 @@ __device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned cha
         qd = l < NJ ? hot[9 + ll] : 0.f;
         elapsed = (int)hot[29];
     }
-    write_outputs(P, env, c, q, qd, elapsed, false);
+    write_outputs(P, env, c, q, qd, elapsed, doit ? TAIL_ZERO : TAIL_KEEP);
 }
 
 }  // namespace pmg

@@ -1,37 +1,162 @@
-"""Multi-GPU sharding of the batched env: one process per GPU, envs split in
-contiguous shards, and ONE collective per batched step -- an RCCL all-gather
-(inside the C-ABI library) of each rank's packed observation shard.
+"""Multi-GPU sharding of the batched env: one process per GPU, envs split in equal contiguous shards, and ONE collective
+per batched step -- an RCCL all-gather (inside the C-ABI library) of each rank's packed observation shard.
 
-Envs never interact (one Bullet world per env in the reference,
-P/envs/base_envs/base_env.py:203-220), so nothing else is exchanged.
-torch.distributed is used only to rendezvous (broadcast the RCCL unique id)
-and, on CPU-only test rigs, as the gloo stand-in for the gather.
+Envs never interact (one Bullet world per env in the reference, P/envs/base_envs/base_env.py:203-220), so nothing else is
+exchanged.  The host side needs three small things from its peers -- the 128-byte RCCL unique id of rank 0, a barrier
+and a max over ranks of a wall time -- and gets them from `Rendezvous`, a few dozen lines of stdlib TCP: no PyTorch, no
+MPI.  (`torch.distributed.run` may still LAUNCH the ranks: only RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT are read.)
 """
+import os
+import pickle
+import socket
+import struct
+import time
+
 import numpy as np
+
+RDV_PORT_OFFSET = 17   # torch.distributed.run keeps its own store on MASTER_PORT: ours listens this far above it
 
 
 def shard_bounds(total_envs, world_size, rank):
-    """Contiguous shard [start, stop) of `rank`: env i lives on rank i // ceil(total / world)."""
-    per = -(-total_envs // world_size)
-    start = min(rank * per, total_envs)
-    return start, min(start + per, total_envs)
+    """Contiguous shard [start, stop) of `rank`.  Shards are EQUAL: the all-gather of the packed rows (ncclAllGather,
+    and its host stand-in) sends the same count from every rank, so a job whose env count does not divide by the world
+    size is refused instead of hanging or corrupting the gather."""
+    if total_envs % world_size != 0:
+        raise ValueError('total_envs=%d is not a multiple of world_size=%d: the packed all-gather needs equal shards '
+                         '(pad the job to %d envs)' % (total_envs, world_size, -(-total_envs // world_size) * world_size))
+    per = total_envs // world_size
+    return rank * per, (rank + 1) * per
 
 
 def make_sharded_env(make_env, total_envs, world_size, rank, **kw):
     """This rank's shard of a `total_envs`-env job; env seeds are those of the global index."""
     start, stop = shard_bounds(total_envs, world_size, rank)
-    if stop <= start:
-        raise ValueError('rank %d of %d has no envs (total %d)' % (rank, world_size, total_envs))
     return make_env(num_envs=stop - start, env_index_offset=start, **kw)
 
 
-def init_rccl(env, rank, world_size, dist=None):
-    """Create the RCCL communicator of `env`'s handle; the unique id travels over torch.distributed."""
-    if dist is None:
-        import torch.distributed as dist
-    uid = [env.handle.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(uid, src=0)
-    env.handle.comm_init(rank, world_size, uid[0])
+def _send(sock, obj):
+    blob = pickle.dumps(obj, protocol=4)
+    sock.sendall(struct.pack('<Q', len(blob)) + blob)
+
+
+def _recv(sock):
+    hdr = b''
+    while len(hdr) < 8:
+        chunk = sock.recv(8 - len(hdr))
+        if not chunk:
+            raise ConnectionError('rendezvous peer closed the connection')
+        hdr += chunk
+    n, = struct.unpack('<Q', hdr)
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(min(1 << 20, n - len(buf)))
+        if not chunk:
+            raise ConnectionError('rendezvous peer closed the connection')
+        buf += chunk
+    return pickle.loads(bytes(buf))
+
+
+class Rendezvous:
+    """Rank 0 listens, everybody else connects; every collective is "all ranks send one object to rank 0, rank 0 sends
+    the list back" -- the ranks call them in the same order, so no threads and no tags are needed.  Control plane only:
+    the data path of the job is the RCCL all-gather inside the library."""
+
+    def __init__(self, rank, world_size, addr=None, port=None, timeout=180.0):
+        self.rank, self.world = int(rank), int(world_size)
+        addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+        if port is None:
+            port = int(os.environ['PMG_RDV_PORT']) if 'PMG_RDV_PORT' in os.environ else int(os.environ.get('MASTER_PORT', '29400')) + RDV_PORT_OFFSET
+        self.peers = []
+        self.sock = None
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr if addr not in ('localhost',) else '127.0.0.1', port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            by_rank = {}
+            while len(by_rank) < self.world - 1:
+                conn, _ = srv.accept()
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                conn.settimeout(timeout)
+                by_rank[_recv(conn)] = conn
+            srv.close()
+            self.peers = [by_rank[r] for r in range(1, self.world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    s = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.05)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            s.settimeout(timeout)
+            _send(s, self.rank)
+            self.sock = s
+
+    @classmethod
+    def from_env(cls, **kw):
+        return cls(int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), **kw)
+
+    def allgather(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] on every rank."""
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            out = [obj] + [_recv(c) for c in self.peers]
+            for c in self.peers:
+                _send(c, out)
+            return out
+        _send(self.sock, obj)
+        return _recv(self.sock)
+
+    def broadcast(self, obj, src=0):
+        return self.allgather(obj if self.rank == src else None)[src]
+
+    def barrier(self):
+        self.allgather(None)
+
+    def max(self, x):
+        return max(self.allgather(x))
+
+    def min(self, x):
+        return min(self.allgather(x))
+
+    def close(self):
+        for c in self.peers:
+            c.close()
+        if self.sock is not None:
+            self.sock.close()
+        self.peers, self.sock = [], None
+
+
+def init_rccl(env, rdv, _force_fail=False):
+    """Create the RCCL communicator of `env`'s handle; rank 0's unique id travels over the rendezvous.  Returns True when
+    EVERY rank has its communicator (all ranks get the same answer, so they can take a fallback together); a failure is
+    reported on stderr by the rank it happened on, never swallowed."""
+    import sys
+    uid = None
+    if rdv.rank == 0 and not _force_fail:
+        try:
+            uid = env.handle.comm_unique_id()
+        except Exception as ex:   # noqa: BLE001
+            print('rank 0: no RCCL unique id (%s)' % ex, file=sys.stderr, flush=True)
+    uid = rdv.broadcast(uid)
+    ok = 0
+    if uid is not None:
+        try:
+            env.handle.comm_init(rdv.rank, rdv.world, uid)
+            ok = 1
+        except Exception as ex:   # noqa: BLE001
+            print('rank %d: RCCL communicator failed (%s)' % (rdv.rank, ex), file=sys.stderr, flush=True)
+    elif _force_fail and rdv.rank == 0:
+        print('rank 0: RCCL communicator failure forced by the caller', file=sys.stderr, flush=True)
+    return rdv.min(ok) == 1
 
 
 def pack_outputs(env, obs, reward, done, goal_achieved):
@@ -52,13 +177,9 @@ def unpack_outputs(dims, packed):
     return obs, packed[:, c[4]], packed[:, c[6]] != 0, packed[:, c[5]] != 0
 
 
-def allgather_host(packed_local, dist=None):
-    """Gather equally-sized packed shards through torch.distributed (gloo on CPU rigs)."""
-    import torch
-    if dist is None:
-        import torch.distributed as dist
-    world = dist.get_world_size()
-    t = torch.from_numpy(packed_local)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    return np.concatenate([x.numpy() for x in out], axis=0)
+def allgather_host(packed_local, rdv):
+    """Host fallback of the all-gather (PCIe + TCP, equal shards): used when no RCCL communicator could be created."""
+    parts = rdv.allgather(np.ascontiguousarray(packed_local))
+    if any(p.shape != parts[0].shape for p in parts):
+        raise ValueError('unequal shards in the packed all-gather: %s' % [p.shape for p in parts])
+    return np.concatenate(parts, axis=0)

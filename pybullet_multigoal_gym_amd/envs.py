@@ -252,6 +252,19 @@ class KukaVecEnv:
         self.handle.set_state(state)
         self._needs_reset = False
 
+    def get_checkpoint(self):
+        """Everything a later set_checkpoint() needs to continue bit-identically: the state rows, the per-env MT19937
+        streams (future goals / orders / curriculum draws) and the host-side curriculum switch."""
+        return {'state': self.handle.get_state(), 'rng': self.handle.get_rng(), 'curriculum_update': self.curriculum_update}
+
+    def set_checkpoint(self, ck):
+        self.handle.set_state(ck['state'])
+        self.handle.set_rng(ck['rng'])
+        if self.curriculum:
+            self.curriculum_update = bool(ck['curriculum_update'])
+            self.handle.curriculum_update(self.curriculum_update)
+        self._needs_reset = False
+
     def set_goal(self, goals, mask=None):
         self.handle.set_goal(goals, mask)
 

@@ -54,6 +54,18 @@ def make_config(task, num_envs, num_block=4, binary_reward=True, joint_control=F
     return c
 
 
+def usable_threads(cap=16):
+    """OpenMP threads worth asking for: the affinity mask capped by the cgroup CPU quota (and by `cap`)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def build():
     subprocess.check_call(['make', '-C', ODIR, '-s'])
 

@@ -13,21 +13,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _worker(rank, world, port, total, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch
     import torch.distributed as dist
     import pybullet_multigoal_gym_amd as pmg
     from pybullet_multigoal_gym_amd import distributed as D
     from pybullet_multigoal_gym_amd._lib import PmgLibrary
-    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)   # the TEST's yardstick
+    rdv = D.Rendezvous(rank, world, addr='127.0.0.1', port=port + 1)                                          # the PRODUCT's rendezvous
     emu = PmgLibrary(os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so'))
     env = D.make_sharded_env(pmg.make_env, total, world, rank, task='reach', seed=11, seed_stride=1, _library=emu)
     start, stop = D.shard_bounds(total, world, rank)
     actions = np.random.RandomState(7).uniform(-1, 1, (total, 3)).astype(np.float32)
     env.reset()
     obs, r, d, info = env.step(actions[start:stop])
-    packed = D.allgather_host(D.pack_outputs(env, obs, r, d, info['goal_achieved']))
+    local = D.pack_outputs(env, obs, r, d, info['goal_achieved'])
+    t = torch.from_numpy(local)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    packed = np.concatenate([x.numpy() for x in parts], axis=0)
+    assert np.array_equal(D.allgather_host(local, rdv), packed)     # the torch-free host gather == gloo's
+    assert rdv.max(float(rank)) == world - 1 and rdv.min(float(rank)) == 0.0 and rdv.broadcast('x' if rank == 0 else None) == 'x'
     # the library's own collective (pmg_comm_init / pmg_allgather_packed): RCCL on the GPU build, the emulator's
     # shared-memory stand-in here -- same call sequence as bench.py --gpus N
-    D.init_rccl(env, rank, world)
+    assert D.init_rccl(env, rdv)
     h = env.handle
     nbytes = total * env.dims.packed_dim * 4
     gathered = h.device_alloc(nbytes)
@@ -40,6 +48,8 @@ def _worker(rank, world, port, total, ret):
         np.save(ret, packed)
         np.save(ret + '.lib.npy', lib_gather)
     env.close()
+    rdv.barrier()
+    rdv.close()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -49,7 +59,9 @@ def test_two_rank_shards_equal_one_unsharded_env(built, tmp_path):
     import oracle_lib as O
     from pybullet_multigoal_gym_amd import distributed as D
     total, world = 4, 2
-    assert [D.shard_bounds(5, 2, r) for r in (0, 1)] == [(0, 3), (3, 5)]
+    assert [D.shard_bounds(6, 2, r) for r in (0, 1)] == [(0, 3), (3, 6)]
+    with pytest.raises(ValueError):      # unequal shards would hang or corrupt the packed all-gather
+        D.shard_bounds(5, 2, 0)
     ret = str(tmp_path / 'packed.npy')
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(world, port, total, ret), nprocs=world, join=True)
@@ -67,17 +79,24 @@ def test_two_rank_shards_equal_one_unsharded_env(built, tmp_path):
     assert np.array_equal(np.load(ret + '.lib.npy'), packed)         # pmg_allgather_packed == the host-side gather
 
 
-@pytest.mark.parametrize('force_fail', [False, True])
-def test_bench_multi_rank_control_flow(built, force_fail):
-    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), on the emulator
-    build: rendezvous, unique-id broadcast, communicator, per-step all-gather, max-over-ranks timing, one JSON line."""
+@pytest.mark.parametrize('launcher,force_fail', [('torchrun', False), ('torchrun', True), ('self', False)])
+def test_bench_multi_rank_control_flow(built, launcher, force_fail):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU) and as a plain
+    `python bench.py --gpus 2` (it spawns its ranks itself), on the emulator build: stdlib rendezvous, unique-id
+    broadcast, communicator, per-step all-gather, max-over-ranks timing, one JSON line -- and no torch in the ranks."""
     import json
     import subprocess
     port = 31000 + os.getpid() % 2000
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--envs-per-gpu', '1', '--lib', os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so')]
+    tail = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--envs-per-gpu', '1', '--no-extras',
+            '--lib', os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so')]
+    if launcher == 'torchrun':
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
     env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env['PMG_ASSERT_NO_TORCH'] = '1'
     if force_fail:   # the communicator cannot be created: every rank must take the labelled host fallback together
         env['PMG_BENCH_FORCE_COMM_FAIL'] = '1'
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
@@ -88,4 +107,16 @@ def test_bench_multi_rank_control_flow(built, force_fail):
     assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak' and d['config']['global_envs'] == 2
     assert d['value'] > 0 and abs(d['value'] - 2 * 2 / (d['ms_per_step'] * 2e-3)) < 1e-6 * d['value']
     assert 'cpu_baseline' not in d and d['roofline']['launches'] == 2
+    assert d['roofline']['kernel_ms_min'] <= d['roofline']['kernel_ms'] <= d['roofline']['kernel_ms_max']
     assert ('FALLBACK' in d['config']['parallelism']) == force_fail
+    assert 'no torch' in out.stderr
+
+
+def test_product_never_imports_torch():
+    src = ''
+    for root in (os.path.join(ROOT, 'pybullet_multigoal_gym_amd'),):
+        for f in os.listdir(root):
+            if f.endswith('.py'):
+                src += open(os.path.join(root, f)).read()
+    src += open(os.path.join(ROOT, 'bench.py')).read()
+    assert 'import torch' not in src and 'from torch' not in src

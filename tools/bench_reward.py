@@ -15,7 +15,21 @@ _lib = None
 if os.environ.get('PMG_BENCH_LIB'):   # kernel A/B: an alternative build of the library
     from pybullet_multigoal_gym_amd._lib import PmgLibrary
     _lib = PmgLibrary(os.environ['PMG_BENCH_LIB'])
-env = pmg.make_env(task='reach', num_envs=64, _library=_lib) if G == 3 else pmg.make_env(task='block_stack', num_block=G // 3, num_envs=64, _library=_lib)
+def env_for_goal_dim(G):
+    """An env whose goal_dim is G: 3 = single-object tasks; 3 nb = block_stack; 3 nb + 4 = block_stack with
+    grip_informed_goal; 1 + 3 nb (+3) = chest_push (with grip_informed_goal)."""
+    if G == 3:
+        return pmg.make_env(task='reach', num_envs=64, _library=_lib)
+    for nb in range(1, 6):
+        for task, kw, g in (('block_stack', {}, 3 * nb), ('block_stack', {'grip_informed_goal': True}, 3 * nb + 4),
+                            ('chest_push', {}, 1 + 3 * nb), ('chest_push', {'grip_informed_goal': True}, 4 + 3 * nb)):
+            if g == G:
+                return pmg.make_env(task=task, num_block=nb, num_envs=64, _library=_lib, **kw)
+    raise SystemExit('no task has goal_dim %d' % G)
+
+
+env = env_for_goal_dim(G)
+assert env.dims.goal_dim == G
 h = env.handle
 ag, dg = h.device_alloc(B * 4 * G), h.device_alloc(B * 4 * G)
 r, ok = h.device_alloc(B * 4), h.device_alloc(B)
@@ -33,7 +47,7 @@ def launch():
 for _ in range(3):
     launch()
 h.sync()
-K = 20
+K = int(os.environ.get('PMG_REWARD_LAUNCHES', '20'))
 t0 = time.perf_counter()
 for _ in range(K):
     launch()
@@ -47,7 +61,7 @@ d = np.linalg.norm(ha.astype(np.float64) - hd, axis=1)
 clear = np.abs(d - 0.05) > 1e-6
 assert np.array_equal(hr[clear], -(d > 0.05).astype(np.float32)[clear]) and np.array_equal(hk[clear] != 0, ~(d > 0.05)[clear])
 gbs = B * (8 * G + 5) / (ms * 1e-3) / 1e9
-print(json.dumps({'kernel': 'pmg_k_reward3' if G == 3 else 'pmg_k_reward (G=%d)' % G, 'items': B, 'bytes_per_item': 8 * G + 5, 'ms': ms, 'items_per_s': B / (ms * 1e-3),
+print(json.dumps({'kernel': 'pmg_k_reward3' if G == 3 else 'pmg_k_reward_flat (G=%d)' % G, 'items': B, 'bytes_per_item': 8 * G + 5, 'read_bytes': B * 8 * G, 'write_bytes': B * 5, 'launches_timed': K, 'timer': 'host perf_counter around K launches + sync (rocprofv3 --kernel-trace figures: profiles/*_reward_kernel_trace.csv)', 'ms': ms, 'items_per_s': B / (ms * 1e-3),
                   'roofline': {'bound': 'hbm', 'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0}}))
 for p_ in (ag, dg, r, ok):
     h.device_free(p_)

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Teacher-forced parity statistics (GPU box): every step the device is re-synchronised to the float64 oracle's state
+(pmg_set_state), both take the same action, and the SINGLE-STEP deviation (100 substeps) is recorded -- the way to test
+chaotic contact code without the chaos.  Prints the max / p99.9 / p99 per quantity; tests/test_gpu_tail_parity.py holds the
+bars derived from these numbers.   tools/teacher_forced.py <task> [N] [T] [f32]   (f32: the float32 ORACLE instead of
+the device, for the precision floor of the same algorithm)"""
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import oracle_lib  # noqa: E402
+
+
+def fields(task, nb):
+    chest = task.startswith('chest')
+    f = {'q_arm': slice(0, 7), 'q_finger': slice(7, 9), 'qd': slice(9, 18)}
+    if chest:
+        f['door_q'] = slice(48, 49)
+        f['door_qd'] = slice(49, 50)
+    return f
+
+
+def block_views(state, nb):
+    b = state[:, 64:64 + 13 * nb].reshape(len(state), nb, 13)
+    return b[..., 0:3], b[..., 3:7], b[..., 7:10], b[..., 10:13]
+
+
+def run(task, N=1024, T=50, kw=None, device=True, threads=16, seed=12345, lib=None):
+    kw = dict(kw or {})
+    nb = 0 if task == 'reach' else (kw.get('num_block', 4) if task.startswith(('block', 'chest')) else 1)
+    o64 = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=threads, **kw)
+    o64.reset()
+    o64.reset()
+    if device:
+        import pybullet_multigoal_gym_amd as pmg
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            dev = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, _library=lib, **kw)
+        dev.reset()
+    else:
+        o32 = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=threads, f32=True, **kw)
+        o32.reset()
+        o32.reset()
+    rs = np.random.RandomState(seed)
+    A = o64.dims.action_dim
+    thr = kw.get('distance_threshold', 0.05)
+    worst = {}
+    flag_mismatch = 0
+    flag_total = 0
+
+    def note(name, err):
+        err = np.asarray(err, np.float64).reshape(len(err), -1).max(1)
+        w = worst.setdefault(name, [])
+        w.append(err)
+
+    for t in range(T):
+        a = rs.uniform(-1, 1, (N, A)).astype(np.float32)
+        s0 = o64.get_state()
+        if device:
+            dev.set_state(s0)
+            od, rd, dd, info = dev.step(a)
+            okd = info['goal_achieved']
+            sd = dev.get_state()
+        else:
+            o32.set_state(s0)
+            od, rd, dd, okd = o32.step(a)
+            sd = o32.get_state()
+        oo, ro, do, oko = o64.step(a)
+        so = o64.get_state()
+        for name, sl in fields(task, nb).items():
+            note(name, np.abs(sd[:, sl] - so[:, sl]))
+        if nb:
+            pd, qd_, vd, wd = block_views(sd, nb)
+            po, qo, vo, wo = block_views(so, nb)
+            note('block_pos', np.abs(pd - po))
+            note('block_quat', np.minimum(np.abs(qd_ - qo), np.abs(qd_ + qo)))
+            note('block_vel', np.abs(vd - vo))
+            note('block_omega', np.abs(wd - wo))
+        note('tip_pos', np.abs(od['observation'][:, :3] - oo['observation'][:, :3]) if not kw.get('joint_control') else
+             np.abs(od['observation'][:, 7:10] - oo['observation'][:, 7:10]))
+        dist = np.linalg.norm(oo['achieved_goal'].astype(np.float64) - oo['desired_goal'], axis=1)
+        clear = np.abs(dist - thr) > 1e-4
+        flag_total += int(clear.sum())
+        flag_mismatch += int((np.asarray(okd)[clear] != np.asarray(oko)[clear]).sum())
+    out = {'task': task, 'kw': kw, 'N': N, 'T': T, 'who': 'device' if device else 'float32 oracle', 'flags_off_threshold': flag_total,
+           'flag_mismatches': flag_mismatch, 'stats': {}}
+    for name, w in worst.items():
+        e = np.concatenate(w)
+        out['stats'][name] = {'max': float(e.max()), 'p99.9': float(np.percentile(e, 99.9)), 'p99': float(np.percentile(e, 99)),
+                              'p50': float(np.percentile(e, 50)), 'n_gt_1e-4': int((e > 1e-4).sum()), 'n_gt_1e-3': int((e > 1e-3).sum()), 'n': int(e.size)}
+    return out
+
+
+if __name__ == '__main__':
+    task = sys.argv[1] if len(sys.argv) > 1 else 'push'
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    dev = not (len(sys.argv) > 4 and sys.argv[4] == 'f32')
+    kw = {'num_block': {'block_stack': 4, 'block_rearrange': 3, 'chest_push': 2, 'chest_pick_and_place': 2}.get(task, 4)} if task.startswith(('block', 'chest')) else {}
+    r = run(task, N, T, kw, device=dev)
+    print(json.dumps(r))
