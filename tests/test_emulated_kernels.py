@@ -119,35 +119,16 @@ def _golden(name):
     return json.load(open(os.path.join(ROOT, 'tests', 'golden', name)))
 
 
-@pytest.mark.parametrize('key,task,kw', [
-    ('rearrange3/0', 'block_rearrange', {}),
-    ('rearrange5_curriculum/3', 'block_rearrange', {'use_curriculum': True}),
-    ('block_stack3_curriculum/3', 'block_stack', {'use_curriculum': True}),
-])
-def test_emulated_multistep_reset_matches_numpy_golden(emu_library, key, task, kw):
-    """The device reset kernel (MT19937, numpy choice(p=) / choice(replace=False), curriculum schedule) against the
-    vectors tools/gen_golden.py produced with the real numpy RandomState -- no oracle in between."""
-    g = _golden('multistep.json')
-    eps = g['episodes'][key]
-    nb = int(''.join(c for c in key.split('/')[0] if c.isdigit()))
-    seed = int(key.split('/')[1])
-    env = _make_quiet(task, emu_library, num_block=nb, seed=seed,
-                          num_goals_to_generate=g['num_goals_to_generate_per_block'] * nb, **kw)
-    # the constructor's reset consumed episode 0 with the update still off (as the reference's constructor does):
-    # the golden sequence counts from the first reset, so start the comparison from a fresh seed
-    if kw.get('use_curriculum'):
-        env.activate_curriculum_update()
-    env.seed(seed)
-    for ep in eps[:12]:
-        o = env.reset()
-        st = env.get_state()[0]
-        for b in range(nb):
-            assert np.array_equal(st[64 + 13 * b:67 + 13 * b], np.float32(ep['blocks'][b]))
-        assert np.array_equal(o['desired_goal'][0], np.float32(ep['desired_goal']))
-        if 'level' in ep:
-            assert env.last_curriculum_level[0] == ep['level'] and env.curriculum_goal_step[0] == ep['goal_step']
-            assert np.array_equal(env.curriculum_prob[0], np.float32(ep['prob']))
-            assert np.array_equal(env.num_generated_goals_per_curriculum[0], np.float32(ep['generated']))
+@pytest.mark.parametrize('name', ['sampling_block_rearrange3_curriculum', 'sampling_block_stack4_curriculum', 'sampling_push',
+                                  'sampling_chest_push2_curriculum'])
+def test_emulated_reset_kernel_replays_reference_sampling(emu_library, name):
+    """The device reset kernel (MT19937, numpy choice(p=) / choice(replace=False), shuffles, rejection loops, curriculum
+    schedule) against what the REFERENCE's own _task_reset / _generate_goal / _generate_curriculum drew for several
+    seeds (tests/golden/ref_sampling_*.json, tools/gen_reference_fixtures.py) -- no oracle in between."""
+    import ref_replay as R
+    fx = R.load(os.path.join(ROOT, 'tests', 'golden', 'ref_%s.json' % name))
+    env = R.ProductAdapter(fx, library=emu_library)
+    R.replay(fx, env, tol_static=2e-5)
     env.close()
 
 

@@ -121,7 +121,7 @@ def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task,
     tip_err = np.abs(o['observation'][:, :3] - a64['observation'][:, :3]).max(1)
     assert np.percentile(tip_err, 90) < 1e-3
     if kw.get('binary_reward', True):
-        assert (r != r64).mean() < 0.05
+        assert (r != r64).mean() <= 0.02      # teacher-forced: no flag differs off the threshold (tests/test_gpu_tail_parity.py); here one of 64 envs may sit ON it
     else:
         assert np.percentile(np.abs(r - r64), 90) < 2e-3 and r.dtype == np.float32
     assert o['observation'].shape == (N, env.dims.observation_dim) and np.isfinite(o['observation']).all()
@@ -270,27 +270,36 @@ def test_chest_curriculum_and_sub_goals_on_device(built, task):
 
 
 def test_multistep_bookkeeping_on_device(built):
-    """Curriculum draws / schedule against the numpy-generated golden vectors, and sub-goal switching against the
-    oracle, through the HIP library (8 envs, seed_stride 0: every env replays the golden sequence)."""
+    """Curriculum draws / schedule against what the REFERENCE's own code drew (tests/golden/ref_sampling_*.json), batched:
+    8 envs with seed_stride 0 must all replay the recorded sequence; and sub-goal switching against the oracle."""
     import json, os, warnings
+    import ref_replay as R
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    g = json.load(open(os.path.join(root, 'tests', 'golden', 'multistep.json')))
     N = 8
-    for key, task in [('rearrange3_curriculum/0', 'block_rearrange'), ('block_stack5_curriculum/3', 'block_stack')]:
-        nb = int(''.join(c for c in key.split('/')[0] if c.isdigit()))
-        seed = int(key.split('/')[1])
+    for name in ('sampling_block_rearrange3_curriculum', 'sampling_block_stack4_curriculum'):
+        fx = R.load(os.path.join(root, 'tests', 'golden', 'ref_%s.json' % name))
+        nb = fx['oracle_kwargs']['num_block']
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            env = pmg.make_env(task=task, num_envs=N, num_block=nb, seed=seed, seed_stride=0, use_curriculum=True,
-                               num_goals_to_generate=g['num_goals_to_generate_per_block'] * nb)
-        env.activate_curriculum_update()
-        env.seed(seed)
-        for ep in g['episodes'][key]:
-            o = env.reset()
-            assert (o['desired_goal'] == np.float32(ep['desired_goal'])).all()
-            assert (env.last_curriculum_level == ep['level']).all() and (env.curriculum_goal_step == ep['goal_step']).all()
-            assert (env.curriculum_prob == np.float32(ep['prob'])).all()
-            assert (env.num_generated_goals_per_curriculum == np.float32(ep['generated'])).all()
+            env = pmg.make_env(task=fx['task'], num_envs=N, seed=0, seed_stride=0, **fx['make_kwargs'])
+        resets = 0
+        for ev in fx['events']:
+            if ev['op'] == 'curriculum_update':
+                (env.activate_curriculum_update if ev['enabled'] else env.deactivate_curriculum_update)()
+            elif ev['op'] == 'seed':
+                env.seed(ev['seed'])
+            elif ev['op'] == 'reset':
+                o = env.reset()
+                want = ev['out']
+                assert (o['desired_goal'] == np.float32(want['obs']['desired_goal'])).all()
+                c = want['curriculum']
+                if 'level' in c:
+                    assert (env.last_curriculum_level == c['level']).all()
+                assert (env.curriculum_goal_step == c['goal_step']).all()
+                assert (env.curriculum_prob == np.float32(c['prob'])).all()
+                assert (env.num_generated_goals_per_curriculum == np.float32(c['generated'])).all()
+                resets += 1
+        assert resets >= 40
         s = env.get_state()
         env.set_state(s)                                   # curriculum tail round-trips through get/set_state
         assert np.array_equal(env.get_state(), s) and s.shape[1] == 64 + 13 * nb + 16
@@ -455,7 +464,8 @@ def test_rccl_single_rank_allgather_and_kernel_timer(built):
     env.close()
 
 
-@pytest.mark.parametrize('task,N,kw', [('pick_and_place', 8192, {'binary_reward': False}),      # BASELINE.json configs[3]
+@pytest.mark.parametrize('task,N,kw', [('pick_and_place', 8192, {'binary_reward': False}),      # BASELINE.json configs[3]: dense ...
+                                       ('pick_and_place', 8192, {'binary_reward': True}),       # ... and binary
                                        ('block_stack', 4096, {'num_block': 4}),                  # configs[4]
                                        ('push', 4096, {})])                                      # configs[2]
 def test_full_size_contact_configs_properties(built, task, N, kw):

@@ -100,3 +100,21 @@ def test_hip_reproduces_reference_session(built, hip_library, path):
     worst = R.replay(fx, env, tol_static=2e-5, threshold_guard=2e-3, **bars)
     env.close()
     print('worst', os.path.basename(path), worst)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The day a machine with pybullet~=3.0.6 + gym~=0.17.3 runs `tools/gen_reference_fixtures.py --real`, the same sessions on
+# the REAL reference land in tests/golden/real_*.json and these tests pin the physics at BASELINE.json's
+# 1e-3.  Until then: skipped, and the physics stays [BULLET-PRIOR] -- "parity unpinned" for that row.
+import glob  # noqa: E402
+
+REAL = sorted(glob.glob(os.path.join(ROOT, 'tests', 'golden', 'real_*.json')))
+
+
+@pytest.mark.skipif(not REAL, reason='no capture from real PyBullet exists (pybullet / gym are absent here): physics parity unpinned')
+@pytest.mark.parametrize('path', REAL or [None])
+def test_oracle_matches_real_pybullet_capture(built, path):
+    fx = R.load(path)
+    env = R.OracleAdapter(fx)
+    R.replay(fx, env, tol_static=1e-3, tol_traj=1e-3, tol_vel=5e-2, threshold_guard=2e-3, check_internal=False)
+    env.close()

@@ -65,8 +65,31 @@ def curriculum_rec(inner):
     return r
 
 
+REAL = False   # --real: the reference on REAL pybullet / gym (wherever those exist); files real_*.json
+
+
+def real_world_state(inner):
+    """What FakeBulletClient.world_state() reads from the oracle, read from a real Bullet client instead."""
+    p, robot = inner._p, inner.robot
+    idx = list(robot.kuka_joint_index) + list(robot.gripper_joint_index)
+    js = [p.getJointState(robot.kuka_body_index, j) for j in idx]
+    st = dict(q=[float(s_[0]) for s_ in js], qd=[float(s_[1]) for s_ in js], blocks=[])
+    names = ['block'] if 'block' in inner.object_bodies else [k for k in getattr(inner, 'block_keys', [])][:getattr(inner, 'num_block', 0)]
+    for k in names:
+        body = inner.object_bodies.get(k)
+        if body is None:
+            continue
+        pos, orn = p.getBasePositionAndOrientation(body)
+        lin, ang = p.getBaseVelocity(body)
+        st['blocks'].append([float(v) for v in tuple(pos) + tuple(orn) + tuple(lin) + tuple(ang)])
+    if getattr(inner, 'chest', False):
+        dq, dqd, _ = inner.chest_robot.jdict[inner.chest_robot.door_joint_name].get_state()
+        st['door'] = [float(dq), float(dqd)]
+    return st
+
+
 def internal_rec(inner):
-    st = fake_bullet.LAST_CLIENT.world_state()
+    st = real_world_state(inner) if REAL else fake_bullet.LAST_CLIENT.world_state()
     st['ee_target'] = flt(inner.robot.end_effector_target)
     st['joint_target'] = flt(inner.robot.joint_state_target)
     if getattr(inner, 'last_order', None) is not None:
@@ -74,20 +97,21 @@ def internal_rec(inner):
     return st
 
 
-def run_session(task, make_kw, oracle_kw, script):
+def run_session(task, make_kw, oracle_kw, script, light=False):
     import pybullet_multigoal_gym as ref
-    fake_bullet.configure(task=task, **oracle_kw)
+    if not REAL:
+        fake_bullet.configure(task=task, **oracle_kw)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         env = ref.make_env(task=task, gripper='parallel_jaw', render=False, **make_kw)
     inner = env.unwrapped
-    client = fake_bullet.LAST_CLIENT
+    client = None if REAL else fake_bullet.LAST_CLIENT
     A = env.action_space.shape[0]
     fx = dict(task=task, make_kwargs=make_kw, oracle_kwargs=oracle_kw, env_id=inner.spec.id,
               max_episode_steps=env._max_episode_steps, action_dim=A,
               action_low=flt(env.action_space.low), action_high=flt(env.action_space.high),
               observation_space={k: list(v.shape) for k, v in env.observation_space.spaces.items()},
-              world_params={k: (list(v) if isinstance(v, tuple) else v) for k, v in client.params.items()},
+              world_params={} if REAL else {k: (list(v) if isinstance(v, tuple) else v) for k, v in client.params.items()},
               after_constructor=dict(internal=internal_rec(inner), curriculum=curriculum_rec(inner)), events=[])
     ev = fx['events']
     rs = np.random.RandomState(12345)
@@ -101,7 +125,12 @@ def run_session(task, make_kw, oracle_kw, script):
                 # (possible with tiny num_goals_to_generate).  The reference dies here; so does the recorded session.
                 ev.append(dict(op='reset', out=dict(error=str(ex))))
                 break
-            ev.append(dict(op='reset', out=dict(obs=obs_rec(o), internal=internal_rec(inner), curriculum=curriculum_rec(inner))))
+            if light:   # sampling sessions: what a reset DRAWS (goal, object poses, order, curriculum), not the whole observation
+                st = internal_rec(inner)
+                ev.append(dict(op='reset', out=dict(obs={k: flt(o[k]) for k in ('achieved_goal', 'desired_goal')},
+                                                    internal={k: st[k] for k in ('blocks', 'order') if k in st}, curriculum=curriculum_rec(inner))))
+            else:
+                ev.append(dict(op='reset', out=dict(obs=obs_rec(o), internal=internal_rec(inner), curriculum=curriculum_rec(inner))))
         elif kind == 'step':
             n = op[1]
             bias = np.asarray(op[2], np.float32) if len(op) > 2 else np.zeros(A, np.float32)
@@ -138,8 +167,9 @@ def run_session(task, make_kw, oracle_kw, script):
                            out=dict(reward=flt(r), reward_dtype=str(r.dtype), goal_achieved=[bool(x) for x in ok])))
         else:
             raise ValueError(kind)
-    fx['bullet_calls'] = dict(client.calls)
-    fx['urdf_fk_max_err'] = client.fk_max_err
+    fx['bullet_calls'] = {} if REAL else dict(client.calls)
+    fx['urdf_fk_max_err'] = 0.0 if REAL else client.fk_max_err
+    fx['physics'] = 'pybullet (the real reference)' if REAL else 'oracle/pmg_oracle.c behind a scripted Bullet client'
     env.close()
     return fx
 
@@ -195,18 +225,57 @@ SESSIONS = [
 ]
 
 
+def sampling(seeds, resets, pre=()):
+    return list(pre) + sum([[('seed', sd)] + [('reset',)] * resets for sd in seeds], [])
+
+
+SEEDS = [0, 1, 2, 3, 12345, 2 ** 31 + 7]
+CUR = dict(use_curriculum=True, num_goals_to_generate=40)
+# many-seed sampling sessions (light records): every draw of every task's reset comes from the reference's own
+# _task_reset / _generate_goal / _generate_curriculum -- nothing about the sampling rules is re-typed anywhere in this repo
+SAMPLING = [
+    ('sampling_reach', 'reach', {}, {}, sampling(SEEDS, 5)),
+    ('sampling_push', 'push', {}, {}, sampling(SEEDS, 5)),
+    ('sampling_pick_and_place', 'pick_and_place', {}, {}, sampling(SEEDS, 8)),
+    ('sampling_slide', 'slide', {}, {}, sampling(SEEDS, 5)),
+    ('sampling_block_stack5', 'block_stack', dict(num_block=5), dict(num_block=5), sampling(SEEDS, 5)),
+    ('sampling_block_stack2', 'block_stack', dict(num_block=2), dict(num_block=2), sampling(SEEDS[:3], 4)),
+    ('sampling_block_stack4_curriculum', 'block_stack', dict(num_block=4, **CUR), dict(num_block=4, **CUR),
+     sampling(SEEDS[:4], 12, pre=[('curriculum_update', True)])),
+    ('sampling_block_rearrange5', 'block_rearrange', dict(num_block=5), dict(num_block=5), sampling(SEEDS, 4)),
+    ('sampling_block_rearrange3_curriculum', 'block_rearrange', dict(num_block=3, **CUR), dict(num_block=3, **CUR),
+     sampling(SEEDS[:4], 12, pre=[('curriculum_update', True)])),
+    ('sampling_chest_push4', 'chest_push', dict(num_block=4), dict(num_block=4), sampling(SEEDS, 4)),
+    ('sampling_chest_push2_curriculum', 'chest_push', dict(num_block=2, **CUR), dict(num_block=2, **CUR),
+     sampling(SEEDS[:4], 12, pre=[('curriculum_update', True)])),
+    ('sampling_chest_pick_and_place3_curriculum_grip', 'chest_pick_and_place', dict(num_block=3, grip_informed_goal=True, **CUR),
+     dict(num_block=3, grip_informed_goal=True, **CUR), sampling(SEEDS[:4], 12, pre=[('curriculum_update', True)])),
+]
+
+
 def main():
-    stubs.install()
-    only = set(sys.argv[1:])
+    global REAL
+    REAL = '--real' in sys.argv
+    if REAL:
+        # wherever pybullet~=3.0.6 and gym~=0.17.3 exist (not this container, not the GPU box): the same sessions on the
+        # REAL reference -> tests/golden/real_*.json, which tests/test_reference_golden.py then holds the oracle and the
+        # device to at BASELINE.json's 1e-3.  UNTESTED here for want of those packages.
+        import gym, pybullet  # noqa: F401, E401
+        sys.path.insert(0, os.environ.get('PMG_REFERENCE_ROOT', '/root/reference'))
+    else:
+        stubs.install()
+    only = set(a for a in sys.argv[1:] if not a.startswith('--'))
     os.makedirs(OUT, exist_ok=True)
     total = 0
-    for name, task, mk, ok, script in SESSIONS:
+    for name, task, mk, ok, script in SESSIONS + SAMPLING:
         if only and name not in only:
             continue
         import gym
         gym.envs.registration.registry.env_specs.clear()   # the reference registers by id: same id, different kwargs otherwise
-        fx = run_session(task, mk, ok, script)
-        path = os.path.join(OUT, 'ref_%s.json' % name)
+        if REAL and name.startswith('sampling_'):
+            continue
+        fx = run_session(task, mk, ok, script, light=name.startswith('sampling_'))
+        path = os.path.join(OUT, ('real_%s.json' if REAL else 'ref_%s.json') % name)
         with open(path, 'w') as f:
             json.dump(fx, f, separators=(',', ':'))
         total += os.path.getsize(path)
