@@ -46,6 +46,30 @@ typedef double real;
 #endif
 
 /* ------------------------------------------------------------------ */
+/* [BULLET-PRIOR] choices, switchable (oracle only; the product compiles the defaults in).  With no PyBullet to ask,
+ * each of these was settled from Bullet 3.0.x's published behaviour; pmgo_set_prior() lets the first real capture
+ * (tools/gen_reference_fixtures.py --real) rank the alternatives instead of starting a debugging session.
+ * NOT switchable, because they are structural: per-substep manifold regeneration (Bullet keeps a persistent
+ * manifold) and the SAT cylinder pairs (Bullet: GJK/EPA).                                                     */
+/* ------------------------------------------------------------------ */
+enum { PRIOR_MOTOR_IMPULSE_DT, PRIOR_LINK_DAMPING, PRIOR_JOINT_ERP, PRIOR_CONTACT_MARGIN, PRIOR_RESIDUAL_THRESHOLD,
+       PRIOR_IK_DAMPING, PRIOR_LINEAR_SLOP, PRIOR_WARM_START, PRIOR_DAMPING_PER_SUBSTEP, PRIOR_FRICTION_DIRS, PRIOR_N };
+static const char* const PRIOR_NAME[PRIOR_N] = {
+    "motor_impulse_dt",     /* 0.04: max motor impulse = force x fixedTimeStep; 0.002 = force x substep */
+    "link_damping",         /* 0.04: btMultiBody linear / angular damping; 0 = none */
+    "joint_erp",            /* 0.2: joint-limit error reduction */
+    "contact_margin",       /* 0.002: speculative contact distance of the regenerated manifold */
+    "residual_threshold",   /* 1e-7: solver early exit; 0 = always all iterations */
+    "ik_damping",           /* 0.5: DLS damping of calculateInverseKinematics */
+    "linear_slop",          /* 1e-5 */
+    "warm_start",           /* 0: non-contact rows start each substep from zero; f in (0, 1] = from f x last substep's impulses */
+    "damping_per_substep",  /* 0: URDF joint damping latched once per stepSimulation; 1 = re-evaluated every substep */
+    "friction_dirs"         /* 2: two btPlaneSpace1 friction rows per contact; 1 = the first of them only */
+};
+static double G_PRIOR[PRIOR_N] = {0.04, 0.04, 0.2, 0.002, 1e-7, 0.5, 1e-5, 0.0, 0.0, 2.0};
+static const double PRIOR_DEFAULT[PRIOR_N] = {0.04, 0.04, 0.2, 0.002, 1e-7, 0.5, 1e-5, 0.0, 0.0, 2.0};
+
+/* ------------------------------------------------------------------ */
 /* constants                                    */
 /* ------------------------------------------------------------------ */
 #define NJ PMG_NJ
@@ -56,14 +80,12 @@ typedef double real;
 #define SUBSTEPS 20                    /* base_env.py:17,219 */
 #define SIM_STEPS 5                    /* kuka.py:223-225 */
 #define SOLVER_ITERS 5                 /* base_env.py:37,218 */
-#define PHYSICS_DT ((real)0.04)        /* base_env.py:217 (m_physicsDeltaTime) */
+#define PHYSICS_DT ((real)G_PRIOR[PRIOR_MOTOR_IMPULSE_DT]) /* base_env.py:217 (m_physicsDeltaTime): clamps motor impulses */
 #define CONTACT_ERP ((real)0.9)        /* base_env.py:216 setDefaultContactERP */
-#define JOINT_ERP ((real)0.2)          /* [BULLET-PRIOR] btContactSolverInfo::m_erp default */
-#define LINEAR_SLOP ((real)1e-5)       /* [BULLET-PRIOR] PyBullet createEmptyDynamicsWorld */
-#define RESIDUAL_THRESHOLD ((real)1e-7)/* [BULLET-PRIOR] m_leastSquaresResidualThreshold */
-#ifndef LINK_DAMPING
-#define LINK_DAMPING ((real)0.04)      /* [BULLET-PRIOR] btMultiBody m_linearDamping/m_angularDamping */
-#endif
+#define JOINT_ERP ((real)G_PRIOR[PRIOR_JOINT_ERP]) /* [BULLET-PRIOR] btContactSolverInfo::m_erp default 0.2 */
+#define LINEAR_SLOP ((real)G_PRIOR[PRIOR_LINEAR_SLOP]) /* [BULLET-PRIOR] PyBullet createEmptyDynamicsWorld: 1e-5 */
+#define RESIDUAL_THRESHOLD ((real)G_PRIOR[PRIOR_RESIDUAL_THRESHOLD]) /* [BULLET-PRIOR] m_leastSquaresResidualThreshold 1e-7 */
+#define LINK_DAMPING ((real)G_PRIOR[PRIOR_LINK_DAMPING]) /* [BULLET-PRIOR] btMultiBody m_linearDamping / m_angularDamping 0.04 */
 #define LIMIT_MAX_IMPULSE ((real)100.0)/* [BULLET-PRIOR] btMultiBodyConstraint m_maxAppliedImpulse */
 #define ARM_KP ((real)0.03)            /* kuka.py:289 */
 #define ARM_KD ((real)1.0)             /* kuka.py:290 */
@@ -72,9 +94,9 @@ typedef double real;
 #define FINGER_LIMIT ((real)0.035)     /* kuka.py:71 */
 #define IK_MAX_ITER 40                 /* kuka.py:278 */
 #define IK_THRESHOLD ((real)1e-5)      /* kuka.py:279 */
-#define IK_DAMPING ((real)0.5)         /* [BULLET-PRIOR] default joint_damping in calculateInverseKinematics */
+#define IK_DAMPING ((real)G_PRIOR[PRIOR_IK_DAMPING]) /* [BULLET-PRIOR] default joint_damping in calculateInverseKinematics: 0.5 */
 #define IK_MAX_STEP ((real)(45.0 * 3.14159265358979323846 / 180.0)) /* [BULLET-PRIOR] MaxAngleDLS */
-#define CONTACT_MARGIN ((real)0.002)   /* build choice: speculative-contact distance */
+#define CONTACT_MARGIN ((real)G_PRIOR[PRIOR_CONTACT_MARGIN]) /* build choice: speculative-contact distance 0.002 */
 #define GBASE_FRICTION ((real)0.5)     /* [BULLET-PRIOR] btCollisionObject default friction (no <contact> tag) */
 #define EDGE_FUDGE ((real)1.05)        /* [BULLET-PRIOR] btBoxBoxDetector fudge_factor */
 #define MAX_CONTACTS 64
@@ -1289,6 +1311,7 @@ typedef struct {
     double cur_prob[NBMAX + 1], cur_count[NBMAX + 1]; /* curriculum_prob, num_generated_goals_per_curriculum (chest: nb + 1 levels) */
     int cur_goal_step;       /* curriculum_goal_step */
     Block blk[NBMAX];
+    real ws_m[NJ], ws_l[NJ]; /* last substep's motor / limit impulses (only read with the warm_start prior) */
     mt19937 rng;
 } World;
 
@@ -1700,6 +1723,13 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
         plane_space(cp->n, t1, t2);
         real* tt[2] = {t1, t2};
         for (int f = 0; f < 2; f++) {
+            if (f == 1 && G_PRIOR[PRIOR_FRICTION_DIRS] == 1) {   /* alternative prior: one friction row only */
+                Row* fr = &fri[2 * c + f];
+                memset(fr, 0, sizeof(*fr));
+                fr->blk[0] = fr->blk[1] = -1;
+                fr->fric_of = c;
+                continue;
+            }
             Row* fr = &fri[2 * c + f];
             row_setup(e, w, &k, &ac, fr, cp->a, cp->b, cp->pa, cp->pb, tt[f], &rel);
             fr->rhs = -rel * fr->diag_inv;
@@ -1713,6 +1743,16 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
     memset(dqd, 0, sizeof(dqd));
     memset(dbl, 0, sizeof(dbl));
     memset(dba, 0, sizeof(dba));
+    if (G_PRIOR[PRIOR_WARM_START] != 0)   /* alternative prior: the non-contact rows start from last substep's impulses */
+        for (int j = 0; j < nn; j++) {
+            Row* r = &nonc[j];
+            int d = 0;
+            while (d < NJ - 1 && r->Jr[d] == 0) d++;
+            real a0 = (real)G_PRIOR[PRIOR_WARM_START] * (r->lo < 0 ? w->ws_m[d] : w->ws_l[d]);
+            a0 = a0 < r->lo ? r->lo : (a0 > r->hi ? r->hi : a0);
+            r->applied = a0;
+            for (int k = 0; k < NJ; k++) dqd[k] += r->dvr[k] * a0;
+        }
     for (int it = 0; it < SOLVER_ITERS; it++) {
         real resid = 0;
         for (int j = 0; j < nn; j++) {
@@ -1739,6 +1779,12 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
             }
         }
         if (resid <= RESIDUAL_THRESHOLD) break;
+    }
+    for (int d = 0; d < NJ; d++) { w->ws_m[d] = 0; w->ws_l[d] = 0; }
+    for (int j = 0; j < nn; j++) {
+        int d = 0;
+        while (d < NJ - 1 && nonc[j].Jr[d] == 0) d++;
+        if (nonc[j].lo < 0) w->ws_m[d] = nonc[j].applied; else w->ws_l[d] = nonc[j].applied;
     }
     for (int d = 0; d < NJ; d++) w->qd[d] += dqd[d];
     /* 5. integrate positions */
@@ -1769,7 +1815,11 @@ static void step_simulation(const pmgo_env* e, World* w)
 {
     real tau[NJ];
     for (int d = 0; d < NJ; d++) tau[d] = -(real)JDAMP[d] * w->qd[d];
-    for (int s = 0; s < SUBSTEPS; s++) substep(e, w, tau);
+    for (int s = 0; s < SUBSTEPS; s++) {
+        if (G_PRIOR[PRIOR_DAMPING_PER_SUBSTEP] != 0)
+            for (int d = 0; d < NJ; d++) tau[d] = -(real)JDAMP[d] * w->qd[d];
+        substep(e, w, tau);
+    }
 }
 
 /* ------------------------------------------------------------------ */
@@ -2641,3 +2691,20 @@ int pmgo_bw_step_simulation(pmgo_env* e)
     step_simulation(e, bw_world(e));
     return PMG_OK;
 }
+
+/* ---- [BULLET-PRIOR] switches (see the table at the top) ---- */
+int pmgo_prior_count(void) { return PRIOR_N; }
+const char* pmgo_prior_name(int i) { return i >= 0 && i < PRIOR_N ? PRIOR_NAME[i] : NULL; }
+int pmgo_set_prior(const char* name, double value)
+{
+    for (int i = 0; i < PRIOR_N; i++)
+        if (strcmp(name, PRIOR_NAME[i]) == 0) { G_PRIOR[i] = value; return PMG_OK; }
+    return PMG_E_INVALID;
+}
+double pmgo_get_prior(const char* name)
+{
+    for (int i = 0; i < PRIOR_N; i++)
+        if (strcmp(name, PRIOR_NAME[i]) == 0) return G_PRIOR[i];
+    return -1;
+}
+void pmgo_reset_priors(void) { memcpy(G_PRIOR, PRIOR_DEFAULT, sizeof(G_PRIOR)); }

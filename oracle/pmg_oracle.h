@@ -78,6 +78,16 @@ int pmgo_bw_block_state(pmgo_env* env, int b, double out[13]);
 int pmgo_bw_ik(pmgo_env* env, const double pos[3], const double quat_xyzw[4], int max_iter, double threshold, double q_out[9]);
 int pmgo_bw_step_simulation(pmgo_env* env);
 
+
+/* ---- [BULLET-PRIOR] switches: process-wide alternatives for the choices this restatement had to make without PyBullet
+ * (names and defaults: the table at the top of pmg_oracle.c).  Set before stepping; pmgo_reset_priors() restores the
+ * defaults, which are what the product compiles in. ---- */
+int pmgo_prior_count(void);
+const char* pmgo_prior_name(int i);
+int pmgo_set_prior(const char* name, double value);
+double pmgo_get_prior(const char* name);
+void pmgo_reset_priors(void);
+
 #ifdef __cplusplus
 }
 #endif

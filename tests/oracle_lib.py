@@ -243,3 +243,28 @@ def rng_probe(seed, n_double, shuffle_n=0):
     p = np.zeros(max(shuffle_n, 1), np.int32)
     lib.pmgo_rng_probe(C.c_uint64(seed), C.c_int(n_double), _fp(d), C.c_int(shuffle_n), _fp(p))
     return d[:n_double], p[:shuffle_n]
+
+
+# ---- [BULLET-PRIOR] switches of the oracle (process-wide; see oracle/pmg_oracle.c) ----
+def prior_names():
+    lib = load()
+    lib.pmgo_prior_name.restype = C.c_char_p
+    return [lib.pmgo_prior_name(i).decode() for i in range(lib.pmgo_prior_count())]
+
+
+def set_prior(name, value, f32=False):
+    lib = load(f32)
+    rc = lib.pmgo_set_prior(name.encode(), C.c_double(float(value)))
+    if rc != 0:
+        raise KeyError(name)
+
+
+def get_prior(name, f32=False):
+    lib = load(f32)
+    lib.pmgo_get_prior.restype = C.c_double
+    return lib.pmgo_get_prior(name.encode())
+
+
+def reset_priors():
+    for f32 in (False, True):
+        load(f32).pmgo_reset_priors()

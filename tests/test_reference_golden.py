@@ -118,3 +118,56 @@ def test_oracle_matches_real_pybullet_capture(built, path):
     env = R.OracleAdapter(fx)
     R.replay(fx, env, tol_static=1e-3, tol_traj=1e-3, tol_vel=5e-2, threshold_guard=2e-3, check_internal=False)
     env.close()
+
+
+ALTERNATIVES = {'motor_impulse_dt': [0.04, 0.002], 'warm_start': [0.0, 0.85], 'link_damping': [0.04, 0.0],
+                'damping_per_substep': [0.0, 1.0], 'residual_threshold': [1e-7, 0.0], 'friction_dirs': [2.0, 1.0]}
+
+
+def rank_priors(fixtures, alternatives=None):
+    """Replay `fixtures` under every combination of the oracle's switchable [BULLET-PRIOR] choices and rank the
+    combinations by the mean trajectory error -- the verdict a first real PyBullet capture gets on day one."""
+    import itertools
+    import oracle_lib
+    alternatives = alternatives or ALTERNATIVES
+    names = sorted(alternatives)
+    table = []
+    try:
+        for combo in itertools.product(*[alternatives[n] for n in names]):
+            for n, v in zip(names, combo):
+                oracle_lib.set_prior(n, v)
+            errs = []
+            for fx in fixtures:
+                env = R.OracleAdapter(fx)
+                try:
+                    w = R.replay(fx, env, tol_static=1e9, tol_traj=1e9, tol_vel=1e9, threshold_guard=1e9, check_internal=False)
+                    errs.append(w['traj'])
+                finally:
+                    env.close()
+            table.append((float(sum(errs) / len(errs)), dict(zip(names, combo))))
+    finally:
+        oracle_lib.reset_priors()
+    return sorted(table, key=lambda t: t[0])
+
+
+def test_prior_switches_change_the_physics_and_reset(built):
+    """The switchable [BULLET-PRIOR] choices exist, move the trajectories, and the defaults (what the product compiles in
+    and what tests/golden/ref_*.json were recorded with) come back after pmgo_reset_priors()."""
+    import oracle_lib
+    assert set(ALTERNATIVES) <= set(oracle_lib.prior_names())
+    fx = R.load(os.path.join(ROOT, 'tests', 'golden', 'ref_push_joint.json'))
+    ranked = rank_priors([fx], {'motor_impulse_dt': [0.04, 0.002], 'warm_start': [0.0, 0.85]})
+    assert ranked[0][1] == {'motor_impulse_dt': 0.04, 'warm_start': 0.0} and ranked[0][0] < 1e-6      # the recorded combination
+    assert ranked[1][0] > 1e-5                                                                          # any other one moves it
+    assert oracle_lib.get_prior('motor_impulse_dt') == 0.04 and oracle_lib.get_prior('warm_start') == 0.0
+    env = R.OracleAdapter(fx)
+    R.replay(fx, env, tol_static=1.5e-7, tol_traj=1.5e-7)
+    env.close()
+
+
+@pytest.mark.skipif(not REAL, reason='no capture from real PyBullet exists: nothing to rank the [BULLET-PRIOR] alternatives against')
+def test_rank_prior_alternatives_against_real_capture(built):
+    ranked = rank_priors([R.load(p) for p in REAL])
+    for err, combo in ranked[:8]:
+        print('%.3e %s' % (err, combo))
+    assert ranked[0][0] < 1e-3, 'no combination of the switchable priors reaches BASELINE.json\'s 1e-3: look at the structural ones (manifold, GJK)'
