@@ -53,7 +53,7 @@ __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst
     float rq = l < NJ ? tau - h : 0.f;
     float qdd = 0.f;
 #pragma unroll
-    for (int j = 0; j < NJ; j++) qdd += minv[j] * wr::bcast(rq, j);
+    for (int j = 0; j < NJ; j++) qdd += minv[j] * wr::bcast_r0(rq, j);
     qd += DT * qdd;
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);

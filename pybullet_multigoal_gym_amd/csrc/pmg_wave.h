@@ -62,6 +62,49 @@ __device__ __forceinline__ void fma2_bcast_c(float v, float c1, float& acc1, flo
 /* does p hold in any lane of the env?  (wave-uniform here) */
 __device__ __forceinline__ bool any_lane(bool p) { return __ballot(p) != 0ull; }
 
+/* ROW-0 broadcasts.  The robot's nine DoFs live in lanes 0..8, i.e. inside the first 16-lane DPP row, and most of the
+ * robot maths is consumed there only.  For those call sites lane SRC is handed out by ONE DPP row_newbcast instead of
+ * v_readlane -> SGPR -> operand (measured: ~25 cycles per dependent readlane + use, ~12 for the DPP form, which can also
+ * ride on the consuming v_fmac).  Lanes 16..63 receive lane SRC of THEIR row: garbage by contract -- callers that need
+ * the value wave-wide (FK hand-over to the pair lanes, tip frame, row-space contact lanes) keep bcast(). */
+#ifndef PMG_NO_R0_DPP
+template <int SRC>
+__device__ __forceinline__ float bcast_r0_c(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + SRC, 0xF, 0xF, true)); }
+__device__ __forceinline__ float bcast_r0(float v, int src)
+{
+    if (__builtin_constant_p(src)) {
+        switch (src & 15) {
+        case 0: return bcast_r0_c<0>(v);   case 1: return bcast_r0_c<1>(v);   case 2: return bcast_r0_c<2>(v);   case 3: return bcast_r0_c<3>(v);
+        case 4: return bcast_r0_c<4>(v);   case 5: return bcast_r0_c<5>(v);   case 6: return bcast_r0_c<6>(v);   case 7: return bcast_r0_c<7>(v);
+        case 8: return bcast_r0_c<8>(v);   case 9: return bcast_r0_c<9>(v);   case 10: return bcast_r0_c<10>(v); case 11: return bcast_r0_c<11>(v);
+        case 12: return bcast_r0_c<12>(v); case 13: return bcast_r0_c<13>(v); case 14: return bcast_r0_c<14>(v); default: return bcast_r0_c<15>(v);
+        }
+    }
+    return bcast(v, src);
+}
+template <int SRC>
+__device__ __forceinline__ void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc1), "+v"(acc2)
+                 : "v"(v), "v"(c1), "v"(c2), "n"(SRC));
+}
+#else
+template <int SRC>
+__device__ __forceinline__ float bcast_r0_c(float v) { return bcast_c<SRC>(v); }
+__device__ __forceinline__ float bcast_r0(float v, int src) { return bcast(v, src); }
+template <int SRC>
+__device__ __forceinline__ void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2) { fma2_bcast_c<SRC>(v, c1, acc1, c2, acc2); }
+#endif
+template <int N>
+__device__ __forceinline__ void bcastn_r0(const float* v, int src, float* out)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) out[k] = bcast_r0(v[k], src);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp(float old, float v)
 {
@@ -209,6 +252,14 @@ __device__ __forceinline__ void fma2_bcast_c(float v, float c1, float& acc1, flo
 }
 /* does p hold in any lane of the caller's env (= row)?  Per lane, diverges by row */
 __device__ __forceinline__ bool any_lane(bool p) { return ((__ballot(p) >> ((int)threadIdx.x & 48)) & 0xFFFFull) != 0ull; }
+/* "row 0" of an env IS its row here */
+template <int SRC>
+__device__ __forceinline__ float bcast_r0_c(float v) { return bcast_c<SRC>(v); }
+__device__ __forceinline__ float bcast_r0(float v, int src) { return bcast(v, src); }
+template <int N>
+__device__ __forceinline__ void bcastn_r0(const float* v, int src, float* out) { bcastn<N>(v, src, out); }
+template <int SRC>
+__device__ __forceinline__ void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2) { fma2_bcast_c<SRC>(v, c1, acc1, c2, acc2); }
 template <int N>
 __device__ __forceinline__ float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }
 template <int N>

@@ -139,6 +139,14 @@ inline void fma2_bcast_c(float v, float c1, float& acc1, float c2, float& acc2)
     acc1 = fmaf(c1, b, acc1);
     acc2 = fmaf(c2, b, acc2);
 }
+/* row-0 broadcasts of the device header: same values in the lanes that are allowed to look */
+template <int SRC>
+inline float bcast_r0_c(float v) { return bcast(v, SRC); }
+inline float bcast_r0(float v, int src) { return bcast(v, src); }
+template <int N>
+inline void bcastn_r0(const float* v, int src, float* out) { bcastn<N>(v, src, out); }
+template <int SRC>
+inline void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2) { fma2_bcast_c<SRC>(v, c1, acc1, c2, acc2); }
 }  // namespace wv
 
 /* row-packed variant (four envs per wave, one per 16-lane row): see the product header.  The fiber scheduler
@@ -204,5 +212,13 @@ inline void fma2_bcast_c(float v, float c1, float& acc1, float c2, float& acc2)
     acc1 = fmaf(c1, b, acc1);
     acc2 = fmaf(c2, b, acc2);
 }
+/* row-0 broadcasts of the device header: same values in the lanes that are allowed to look */
+template <int SRC>
+inline float bcast_r0_c(float v) { return bcast(v, SRC); }
+inline float bcast_r0(float v, int src) { return bcast(v, src); }
+template <int N>
+inline void bcastn_r0(const float* v, int src, float* out) { bcastn<N>(v, src, out); }
+template <int SRC>
+inline void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2) { fma2_bcast_c<SRC>(v, c1, acc1, c2, acc2); }
 }  // namespace wr
 #endif
