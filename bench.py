@@ -150,6 +150,10 @@ def main():
     from pybullet_multigoal_gym_amd._lib import PmgLibrary
     from pybullet_multigoal_gym_amd.distributed import Rendezvous, init_rccl
 
+    # RCCL prints a version banner on fd 1 when a communicator comes up: keep fd 1 for the ONE JSON line, send the rest of
+    # this process's stdout to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -284,7 +288,7 @@ def main():
             out['host_api'] = host
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.task)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if os.environ.get('PMG_ASSERT_NO_TORCH') and rank == 0:   # test hook: the ranks run without PyTorch
         assert 'torch' not in sys.modules, 'torch was imported by a bench rank'
         print('no torch in rank 0 (%d modules loaded)' % len(sys.modules), file=sys.stderr, flush=True)

@@ -2,7 +2,7 @@
 # Run on the GPU box: calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE on kernels with KNOWN byte counts (MI355X_MICROARCH.md
 # "HBM": FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950; other widths and WRITE_SIZE are uncalibrated).
 #   G = 3  -> pmg_k_reward3      : dwordx4 loads / stores  (16 B per lane)
-#   G = 5  -> pmg_k_reward_flat<1>: dword loads, dword + byte stores (the access width of the step kernels)
+#   G = 7  -> pmg_k_reward_flat<1>: dword loads, dword + byte stores (the access width of the step kernels)
 # Also records the reward kernels under --kernel-trace (their duration by the profiler, not by host timers).
 #   tools/calibrate_counters.sh [round-tag]
 set -u
@@ -12,7 +12,7 @@ out=$root/gpurun_out/calib; rm -rf $out; mkdir -p $out $root/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp
 export PMG_REWARD_LAUNCHES=4
 B=$((1<<26))
-for G in 3 5 12; do
+for G in 3 7 12; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$G -- python $root/tools/bench_reward.py $B $G > $out/trace_$G.json 2> $out/trace_$G.err
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $out/pmc_${c}_$G -- python $root/tools/bench_reward.py $B $G > $out/pmc_${c}_$G.json 2> $out/pmc_${c}_$G.err
@@ -24,7 +24,7 @@ tag, B = sys.argv[1], int(sys.argv[2])
 root = os.getcwd()
 out = os.path.join(root, 'gpurun_out', 'calib')
 res = {'items': B, 'kernels': {}}
-for G in (3, 5, 12):
+for G in (3, 7, 12):
     per = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         vals = {}
@@ -50,9 +50,9 @@ for G in (3, 5, 12):
         k['frac_of_8TBps'] = k['GBps_by_kernel_trace'] / 8000.0
     res['kernels']['G%d' % G] = k
 res['fetch_factor_dwordx4'] = res['kernels']['G3']['fetch_factor']
-res['fetch_factor_dword'] = res['kernels']['G5']['fetch_factor']
-res['write_factor_dword'] = res['kernels']['G5']['write_factor']
-res['note'] = 'factor = known bytes / counter bytes on a 64 Mi-item launch far beyond the 256 MiB Infinity Cache; G=3 streams dwordx4, G=5 dwords'
+res['fetch_factor_dword'] = res['kernels']['G7']['fetch_factor']
+res['write_factor_dword'] = res['kernels']['G7']['write_factor']
+res['note'] = 'factor = known bytes / counter bytes on a 64 Mi-item launch far beyond the 256 MiB Infinity Cache; G=3 streams dwordx4, G=7 dwords'
 json.dump(res, open(os.path.join(root, 'gpurun_out', 'profiles', '%s_counter_calibration.json' % tag), 'w'), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != 'kernels'}))
 for g, k in res['kernels'].items():

@@ -50,8 +50,9 @@ if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
     for cand in (os.path.join(root, 'gpurun_out', 'profiles', '%s_counter_calibration.json' % tag), os.path.join(root, 'profiles', '%s_counter_calibration.json' % tag)):
         if os.path.exists(cand):
             c = json.load(open(cand))
-            cal = {'fetch_dword': c['fetch_factor_dword'], 'write_dword': c['write_factor_dword'], 'source': os.path.basename(cand)}
-            break
+            if c.get('fetch_factor_dword') and c.get('write_factor_dword'):
+                cal = {'fetch_dword': c['fetch_factor_dword'], 'write_dword': c['write_factor_dword'], 'source': os.path.basename(cand)}
+                break
     json.dump({'task': task, 'envs_per_gpu': N,
                'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --task %s --envs-per-gpu %d --steps 50 --warmup 5 --no-cpu-baseline --no-extras' % (task, N),
                'kernel': 'pmg_k_step family (+ redo)', 'FETCH_SIZE_KiB': fk, 'WRITE_SIZE_KiB': wk, 'calibration': cal,

@@ -1,28 +1,42 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun) after a kernel change: rocprofv3 kernel stats + counter passes for every task
-# (tools/profile.sh), then every committed bench line against those fresh counters.  Everything lands under
+# Run on the GPU box (via gpurun) after a kernel change: counter calibration, rocprofv3 kernel stats + counter passes for
+# every task (tools/profile.sh), then every committed bench line against those fresh counters.  Everything lands under
 # gpurun_out/evidence/ with the names used in profiles/; copy it over with `cp gpurun_out/evidence/* profiles/`.
-#   tools/refresh_evidence.sh [round-tag]
+#   tools/refresh_evidence.sh [round-tag] [tasks...]
 set -u
-tag=${1:-r01}
+tag=${1:-r02}
+shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
 out=$root/gpurun_out/evidence
-rm -rf $out; mkdir -p $out
-tasks="reach push slide pick_and_place block_stack block_rearrange chest_push chest_pick_and_place"
+rm -rf $out; mkdir -p $out $root/gpurun_out/profiles
+tasks=${*:-reach push slide pick_and_place block_stack block_rearrange chest_push chest_pick_and_place}
+# 1. FETCH_SIZE / WRITE_SIZE calibration on kernels with known byte counts + the reward kernels under --kernel-trace
+bash tools/calibrate_counters.sh $tag > $out/${tag}_calibration.log 2>&1
+cp gpurun_out/profiles/${tag}_counter_calibration.json gpurun_out/profiles/${tag}_reward_G*_kernel_stats.csv $out/ 2>/dev/null
+cp gpurun_out/profiles/${tag}_counter_calibration.json profiles/ 2>/dev/null     # profile_summarise.py applies the factors
+# 2. per-task kernel stats and counters
 for t in $tasks; do
   bash tools/profile.sh $t $tag > /dev/null 2>&1
   cp gpurun_out/profiles/${tag}_${t}4096_* $out/ 2>/dev/null
   cp gpurun_out/profiles/${tag}_${t}4096_* profiles/ 2>/dev/null     # bench.py reads the committed counter passes
 done
+# 3. the bench lines (headline = the default command)
 python bench.py > $out/${tag}_bench_reach4096.json 2>/dev/null
-for t in push slide pick_and_place block_stack block_rearrange chest_push chest_pick_and_place; do
+python bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_reach4096_driver_command.json 2>/dev/null
+for t in $tasks; do
+  [ $t = reach ] && continue
   python bench.py --task $t --steps 100 --warmup 10 > $out/${tag}_bench_${t}4096.json 2>/dev/null
 done
 python bench.py --task pick_and_place --envs-per-gpu 8192 --dense-reward --steps 100 --warmup 10 > $out/${tag}_bench_pick_and_place8192_dense.json 2>/dev/null
-python bench.py --episode-steps 10 --no-cpu-baseline > $out/${tag}_bench_reach4096_short_episodes.json 2>/dev/null
-PMG_PACKED=0 python bench.py --no-cpu-baseline > $out/${tag}_bench_reach4096_one_env_per_wave.json 2>/dev/null
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_default -- python $root/bench.py > /dev/null 2>&1 )
+python bench.py --task pick_and_place --envs-per-gpu 8192 --steps 100 --warmup 10 --no-cpu-baseline > $out/${tag}_bench_pick_and_place8192_binary.json 2>/dev/null
+python bench.py --episode-steps 10 --no-cpu-baseline --no-extras > $out/${tag}_bench_reach4096_short_episodes.json 2>/dev/null
+PMG_PACKED=0 python bench.py --no-cpu-baseline --no-extras > $out/${tag}_bench_reach4096_one_env_per_wave.json 2>/dev/null
+for n in 8192 16384 32768 65536; do
+  python bench.py --envs-per-gpu $n --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $out/${tag}_bench_reach${n}.json 2>/dev/null
+done
+PMG_BENCH_FORCE_DIST=1 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $out/${tag}_bench_reach4096_one_rank_rccl_path.json 2>/dev/null
+# 4. rocprofv3 --kernel-trace --stats of the DEFAULT command (the one the driver's line comes from)
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_default -- python $root/bench.py --no-cpu-baseline > /dev/null 2>&1 )
 cp $root/gpurun_out/prof_default/*/*_kernel_stats.csv $out/${tag}_reach4096_default_command_kernel_stats.csv 2>/dev/null
-python tools/bench_reward.py > $out/${tag}_reward_kernel.log 2>&1
 ls $out | wc -l
