@@ -161,6 +161,9 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
 /* one 1024-thread workgroup partitions all envs (stable, no atomics): per-wave ballots, counts of
  * every (chunk, wave) tile in LDS, then each tile scatters at its exclusive prefix */
 constexpr int PLAN_THREADS = 1024, PLAN_MAX_TILES = 1024;
+#ifndef PMG_FD_DIV
+#define PMG_FD_DIV 8
+#endif
 /* class of an env for the launch order: 0 = first list (one env per wavefront, full contact store), 1 / 2 = second
  * list (fast path).  With free objects the fast-path envs are grouped by whether the fingers are down at the table
  * (class 1) or up (class 2): the four envs of a packed wavefront then mostly walk the same contact code paths */
@@ -189,8 +192,14 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
     }
     __syncthreads();
     const int tiles = chunks * waves < PLAN_MAX_TILES ? chunks * waves : PLAN_MAX_TILES;
-    int n1 = 0;
-    for (int t = 0; t < tiles; t++) n1 += cnt1[t];          /* class 2 starts behind all of class 1 in the second list */
+    int n1 = 0, n0all = 0;
+    for (int t = 0; t < tiles; t++) { n1 += cnt1[t]; n0all += cnt0[t]; }   /* class 2 starts behind all of class 1 in the second list */
+    /* one free object, fingers down at the table (class 1: 8 more contacts = 24 more rows per sweep): such an env holds
+     * its packed wavefront back for the whole step, alone on a wavefront it solves them in row space.  Worth a wavefront
+     * each only while they are few (pick_and_place: +12 %; push / slide, where a fifth of the batch is down there at
+     * any time: -24 %), so the whole class moves to the first list, behind class 0, when it is under 1 / PMG_FD_DIV of
+     * the batch */
+    const bool promote = PMG_FD_DIV > 0 && P.nb == 1 && !P.joint_control && n1 * PMG_FD_DIV <= P.n_envs;
     for (int c = 0; c < chunks; c++) {
         int tile = c * waves + wave;
         int env = c * PLAN_THREADS + tid;
@@ -199,14 +208,15 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
         int b0 = 0, b1 = 0, b2 = 0;
         for (int t = 0; t < tile && t < tiles; t++) { b0 += cnt0[t]; b1 += cnt1[t]; b2 += cnt2[t]; }
         if (cls == 0) P.sched[2 + b0 + __popcll(m0 & below)] = env;
+        else if (cls == 1 && promote) P.sched[2 + n0all + b1 + __popcll(m1 & below)] = env;
         else if (cls == 1) P.sched[2 + P.n_envs + b1 + __popcll(m1 & below)] = env;
-        else if (cls == 2) P.sched[2 + P.n_envs + n1 + b2 + __popcll(m2 & below)] = env;
+        else if (cls == 2) P.sched[2 + P.n_envs + (promote ? 0 : n1) + b2 + __popcll(m2 & below)] = env;
     }
     if (tid == 0) {
         int n0 = 0, n2 = 0;
         for (int t = 0; t < tiles; t++) { n0 += cnt0[t]; n2 += cnt2[t]; }
-        P.sched[0] = n0;
-        P.sched[1] = n1 + n2;
+        P.sched[0] = promote ? n0 + n1 : n0;
+        P.sched[1] = promote ? n2 : n1 + n2;
         P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
     }
 }
