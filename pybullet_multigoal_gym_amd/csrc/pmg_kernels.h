@@ -192,14 +192,16 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
     }
     __syncthreads();
     const int tiles = chunks * waves < PLAN_MAX_TILES ? chunks * waves : PLAN_MAX_TILES;
-    int n1 = 0, n0all = 0;
-    for (int t = 0; t < tiles; t++) { n1 += cnt1[t]; n0all += cnt0[t]; }   /* class 2 starts behind all of class 1 in the second list */
+    int n1 = 0, n0all = 0, n2all = 0;
+    for (int t = 0; t < tiles; t++) { n1 += cnt1[t]; n0all += cnt0[t]; n2all += cnt2[t]; }   /* class 2 starts behind all of class 1 in the second list */
     /* one free object, fingers down at the table (class 1: 8 more contacts = 24 more rows per sweep): such an env holds
      * its packed wavefront back for the whole step, alone on a wavefront it solves them in row space.  Worth a wavefront
      * each only while they are few (pick_and_place: +12 %; push / slide, where a fifth of the batch is down there at
      * any time: -24 %), so the whole class moves to the first list, behind class 0, when it is under 1 / PMG_FD_DIV of
-     * the batch */
-    const bool promote = PMG_FD_DIV > 0 && P.nb == 1 && !P.joint_control && n1 * PMG_FD_DIV <= P.n_envs;
+     * the batch AND the step then still fits 1.5 wavefronts per SIMD (1024 SIMDs; at 8192 envs the packed wavefronts
+     * alone are two per SIMD and the extra one-env wavefronts cost more than they save: 1.74 -> 1.65 M) */
+    const bool promote = PMG_FD_DIV > 0 && P.nb == 1 && !P.joint_control && n1 * PMG_FD_DIV <= P.n_envs &&
+                         n0all + n1 + ((n2all + 3) >> 2) <= 1536;
     for (int c = 0; c < chunks; c++) {
         int tile = c * waves + wave;
         int env = c * PLAN_THREADS + tid;
