@@ -12,6 +12,8 @@
 #ifndef PMG_CONTACT_H
 #define PMG_CONTACT_H
 
+#include <type_traits>
+
 #include "pmg_device.h"
 
 #define WV wv
