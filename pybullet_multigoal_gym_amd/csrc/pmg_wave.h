@@ -59,6 +59,26 @@ __device__ __forceinline__ void fma2_bcast_c(float v, float c1, float& acc1, flo
     acc1 = fmaf(c1, b, acc1);
     acc2 = fmaf(c2, b, acc2);
 }
+/* HALF-ROW broadcasts: lane SRC8 (0..7) of every 8-lane half row to its own half row -- two bank-masked DPP
+ * row_newbcast operations (banks 0-1 take lane SRC8 of the 16-lane row, banks 2-3 lane 8 + SRC8).  A block of the
+ * multi-block layouts owns one half row (pmg_contact_body.inc: LaneDof). */
+template <int SRC8>
+__device__ __forceinline__ float half_bcast_c(float v)
+{
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + SRC8, 0xF, 0x3, false);
+    r = __builtin_amdgcn_update_dpp(r, __float_as_int(v), 0x158 + SRC8, 0xF, 0xC, false);
+    return __int_as_float(r);
+}
+/* acc += c * v[lane SRC8 of my half row] */
+template <int SRC8>
+__device__ __forceinline__ void half_fma_bcast_c(float v, float c, float& acc)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_fmac_f32_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xc"
+                 : "+v"(acc)
+                 : "v"(v), "v"(c), "n"(SRC8), "n"(8 + SRC8));
+}
 /* does p hold in any lane of the env?  (wave-uniform here) */
 __device__ __forceinline__ bool any_lane(bool p) { return __ballot(p) != 0ull; }
 
@@ -252,6 +272,11 @@ __device__ __forceinline__ void fma2_bcast_c(float v, float c1, float& acc1, flo
 }
 /* does p hold in any lane of the caller's env (= row)?  Per lane, diverges by row */
 __device__ __forceinline__ bool any_lane(bool p) { return ((__ballot(p) >> ((int)threadIdx.x & 48)) & 0xFFFFull) != 0ull; }
+/* (the multi-block layouts are never packed; these keep the shared sources compiling) */
+template <int SRC8>
+__device__ __forceinline__ float half_bcast_c(float v) { return wv::half_bcast_c<SRC8>(v); }
+template <int SRC8>
+__device__ __forceinline__ void half_fma_bcast_c(float v, float c, float& acc) { wv::half_fma_bcast_c<SRC8>(v, c, acc); }
 /* "row 0" of an env IS its row here */
 template <int SRC>
 __device__ __forceinline__ float bcast_r0_c(float v) { return bcast_c<SRC>(v); }

@@ -130,6 +130,16 @@ inline unsigned long long ballot(bool p)
     exchange_done();
     return m;
 }
+template <int SRC8>
+inline float half_bcast_c(float v)
+{
+    exchange_put<1>(&v);
+    float r = xbuf()[(lane() & ~7) + SRC8];
+    exchange_done();
+    return r;
+}
+template <int SRC8>
+inline void half_fma_bcast_c(float v, float c, float& acc) { acc = fmaf(c, half_bcast_c<SRC8>(v), acc); }
 inline unsigned any_row_mask(bool p) { return (unsigned)(ballot(p) & 0xFFFFull); }
 inline bool any_lane(bool p) { return ballot(p) != 0ull; }
 template <int SRC>
@@ -203,6 +213,10 @@ inline unsigned long long ballot(bool p)
 inline void opaque(int& i) { (void)i; }
 /* the device ORs the four rows (a wave-uniform mask that only decides which rows get a -- possibly empty -- visit);
  * rows of the emulator may have diverged, so each row answers for itself: same results, fewer empty visits */
+template <int SRC8>
+inline float half_bcast_c(float v) { return wv::half_bcast_c<SRC8>(v); }
+template <int SRC8>
+inline void half_fma_bcast_c(float v, float c, float& acc) { wv::half_fma_bcast_c<SRC8>(v, c, acc); }
 inline unsigned any_row_mask(bool p) { return (unsigned)ballot(p); }
 inline bool any_lane(bool p) { return ballot(p) != 0ull; }
 template <int SRC>
