@@ -28,6 +28,22 @@ def emu_library(built):
 
 
 @pytest.fixture(scope='session')
+def emu_library_small_rowspace(built, tmp_path_factory):
+    """The emulator build of the product sources with the row-space solve of the one-object kernel limited to 4 contacts:
+    an ordinary scene (object + fingers on the table) then takes the path of an env with MORE contacts than that solve
+    holds (object x table run in row space + LDS rows for the rest)."""
+    import subprocess
+    from pybullet_multigoal_gym_amd._lib import PmgLibrary
+    out = str(tmp_path_factory.mktemp('emu') / 'libpmg_emu_small.so')
+    emu = os.path.join(ROOT, 'tests', 'emu')
+    src = os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc')
+    subprocess.check_call(['g++', '-O2', '-fPIC', '-std=c++17', '-I' + emu, '-I' + src, '-Wno-unknown-pragmas', '-DPMG_OBJ_ROWSPACE_MAXC=4',
+                           '-shared', '-o', out, os.path.join(emu, 'hip_emu.cpp'), os.path.join(emu, 'pmg_probe.cpp'),
+                           os.path.join(src, 'pmg_api.cpp'), '-x', 'c++', os.path.join(src, 'pmg_kernels.hip'), '-lrt'])
+    return PmgLibrary(out)
+
+
+@pytest.fixture(scope='session')
 def hip_library(built):
     from pybullet_multigoal_gym_amd._lib import default_library
     return default_library()

@@ -114,6 +114,44 @@ def test_emulated_gripper_base_contact_matches_oracle(emu_library):
     env.close()
 
 
+def test_emulated_stacked_blocks_behind_the_table_run_match_oracle(emu_library):
+    """The block x table run is solved in row space (table_run_*), the rows behind it (block x block, finger x block) as LDS
+    rows that move the same blocks: a block dropped onto another one, then the closed gripper pressed onto the stack --
+    the run's unclamped impulses must be re-derived from the velocity changes at every phase change."""
+    env = _make_quiet('block_stack', emu_library, num_block=2, seed=3)
+    ora = O.OracleEnv('block_stack', 1, num_block=2, seed_base=3, seed_stride=1)
+    ora.reset()
+    env.reset(), ora.reset()
+    st = ora.get_state().copy()
+    st[0, 64:77] = [-0.52, 0.0, 0.175, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]                     # block 0 on the table under the tip
+    st[0, 77:90] = [-0.515, 0.004, 0.175 + 0.0305, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]         # block 1 half a millimetre above it, offset
+    st[0, 18:21] = [-0.52, 0.0, 0.26]
+    env.set_state(st), ora.set_state(st)
+    for a in ([0, 0, -1, 1], [0, 0, -1, 1], [0, 0.3, -1, 1]):
+        a = np.float32(a).reshape(1, -1)
+        o, r, d, _ = env.step(a)
+        oo, ro, do, _ = ora.step(a)
+    se, so = env.get_state()[0], ora.get_state()[0]
+    assert np.abs(se[:9] - so[:9]).max() < 5e-5
+    assert np.abs(se[64:71] - so[64:71]).max() < 2e-4 and np.abs(se[77:84] - so[77:84]).max() < 2e-4
+    assert so[79] > 0.19                                          # block 1 rests on block 0 (not fallen through, not thrown off)
+    env.close()
+
+
+def test_emulated_object_with_more_contacts_than_the_row_space_solve_holds(emu_library_small_rowspace):
+    """One free object, one env per wavefront: up to 16 contacts are solved in row space; beyond that the object x table run
+    goes to row space and the rest stays LDS rows built one per lane (object_run_*, build_rows_by_lane).  A build with the
+    limit lowered to 4 contacts takes that path as soon as the fingers touch the table next to the object they squeeze."""
+    env, ora = _pair(emu_library_small_rowspace, 'pick_and_place')
+    st = ora.get_state().copy()
+    st[0, 64:67] = [-0.52, 0.0, 0.175]
+    st[0, 18:21] = [-0.52, 0.0, 0.176]
+    env.set_state(st), ora.set_state(st)
+    so = _drive(env, ora, [[0, 0, -1, 1], [0, 0, -1, -1]])             # (a third, sliding step decorrelates in float32 on the LDS-row path, old or new)
+    assert abs(so[66] - 0.175) < 5e-3                                  # the object stays on the table between the fingers
+    env.close()
+
+
 def _golden(name):
     import json
     return json.load(open(os.path.join(ROOT, 'tests', 'golden', name)))
