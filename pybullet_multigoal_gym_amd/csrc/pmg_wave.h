@@ -175,6 +175,16 @@ __device__ __forceinline__ float sum_rows(float v)
     for (int r = 1; r < NR; r++) s += bcast(v, 16 * r);
     return s;
 }
+/* sum over all 64 lanes through the wave-level DPP broadcasts (row_bcast:15 hands lane 15 of rows 0 / 2 to rows 1 / 3,
+ * row_bcast:31 lane 31 to rows 2 / 3; both exist on gfx950, tools/probe_dpp.hip): row butterfly, two DPP adds, ONE
+ * v_readlane of lane 63 -- instead of four v_readlane and three dependent adds (sum_all).  Uniform result. */
+__device__ __forceinline__ float sum_wave(float v)
+{
+    v = row_sum(v);
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return bcast(v, 63);
+}
 /* sum over all 64 lanes, uniform result */
 __device__ __forceinline__ float sum_all(float v)
 {
@@ -298,6 +308,7 @@ __device__ __forceinline__ float max_row0(float v) { return wv::row_max(v); }
 template <int NR>
 __device__ __forceinline__ float sum_rows(float v) { return wv::row_sum(v); }
 __device__ __forceinline__ float sum_all(float v) { return wv::row_sum(v); }
+__device__ __forceinline__ float sum_wave(float v) { return wv::row_sum(v); }
 __device__ __forceinline__ float max_all(float v) { return wv::row_max(v); }
 /* v is uniform over the ROW: the test stays per lane and control flow diverges by row */
 __device__ __forceinline__ bool uniform_positive(float v) { return v > 0.f; }

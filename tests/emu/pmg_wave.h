@@ -113,6 +113,13 @@ inline float sum_all(float v)
     float t[4] = {bcast(v, 0), bcast(v, 16), bcast(v, 32), bcast(v, 48)};
     return (t[0] + t[1]) + (t[2] + t[3]);
 }
+/* the device's association order: (r1 + r0) and (r3 + r2) by row_bcast:15, then their sum by row_bcast:31 */
+inline float sum_wave(float v)
+{
+    v = row_sum(v);
+    float t[4] = {bcast(v, 0), bcast(v, 16), bcast(v, 32), bcast(v, 48)};
+    return (t[3] + t[2]) + (t[1] + t[0]);
+}
 inline float max_all(float v)
 {
     v = row_max(v);
@@ -198,6 +205,7 @@ inline float max_row0(float v) { return wv::row_max(v); }
 template <int NR>
 inline float sum_rows(float v) { return wv::row_sum(v); }
 inline float sum_all(float v) { return wv::row_sum(v); }
+inline float sum_wave(float v) { return wv::row_sum(v); }
 inline float max_all(float v) { return wv::row_max(v); }
 inline bool uniform_positive(float v) { return v > 0.f; }
 inline unsigned long long ballot(bool p)
