@@ -2,8 +2,10 @@
 """Teacher-forced parity statistics (GPU box): every step the device is re-synchronised to the float64 oracle's state
 (pmg_set_state), both take the same action, and the SINGLE-STEP deviation (100 substeps) is recorded -- the way to test
 chaotic contact code without the chaos.  Prints the max / p99.9 / p99 per quantity; tests/test_gpu_tail_parity.py holds the
-bars derived from these numbers.   tools/teacher_forced.py <task> [N] [T] [f32]   (f32: the float32 ORACLE instead of
-the device, for the precision floor of the same algorithm)"""
+bars derived from these numbers.   tools/teacher_forced.py <task> [N] [T] [f32] [scripted]   (f32: the float32 ORACLE
+instead of the device, for the precision floor of the same algorithm; scripted: the actions come from the task-solving
+controllers of tools/scripted_policies.py, fed with the float64 oracle's observations -- grasp, lift, carry, push, stack,
+open-the-door-and-drop -- instead of the random policy, so the gripper-on-object solver paths are the ones compared)"""
 import json
 import os
 import sys
@@ -30,12 +32,15 @@ def block_views(state, nb):
     return b[..., 0:3], b[..., 3:7], b[..., 7:10], b[..., 10:13]
 
 
-def run(task, N=1024, T=50, kw=None, device=True, threads=16, seed=12345, lib=None):
+def run(task, N=1024, T=50, kw=None, device=True, threads=16, seed=12345, lib=None, policy=None, keep_schedule=False):
+    """policy: None = uniform random actions, else an object with act(obs) (tools/scripted_policies.py) driven by the
+    float64 oracle's observations.  keep_schedule: also count, per step, the envs on the device's launch lists."""
     kw = dict(kw or {})
     nb = 0 if task == 'reach' else (kw.get('num_block', 4) if task.startswith(('block', 'chest')) else 1)
     o64 = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=threads, **kw)
     o64.reset()
-    o64.reset()
+    obs64 = o64.reset()
+    sched = {}
     if device:
         import pybullet_multigoal_gym_amd as pmg
         with warnings.catch_warnings():
@@ -59,18 +64,22 @@ def run(task, N=1024, T=50, kw=None, device=True, threads=16, seed=12345, lib=No
         w.append(err)
 
     for t in range(T):
-        a = rs.uniform(-1, 1, (N, A)).astype(np.float32)
+        a = rs.uniform(-1, 1, (N, A)).astype(np.float32) if policy is None else policy.act(obs64)
         s0 = o64.get_state()
         if device:
             dev.set_state(s0)
             od, rd, dd, info = dev.step(a)
             okd = info['goal_achieved']
             sd = dev.get_state()
+            if keep_schedule:
+                for key, v in dev.handle.schedule().items():
+                    sched[key] = sched.get(key, 0) + len(v)
         else:
             o32.set_state(s0)
             od, rd, dd, okd = o32.step(a)
             sd = o32.get_state()
         oo, ro, do, oko = o64.step(a)
+        obs64 = oo
         so = o64.get_state()
         for name, sl in fields(task, nb).items():
             note(name, np.abs(sd[:, sl] - so[:, sl]))
@@ -88,7 +97,8 @@ def run(task, N=1024, T=50, kw=None, device=True, threads=16, seed=12345, lib=No
         flag_total += int(clear.sum())
         flag_mismatch += int((np.asarray(okd)[clear] != np.asarray(oko)[clear]).sum())
     out = {'task': task, 'kw': kw, 'N': N, 'T': T, 'who': 'device' if device else 'float32 oracle', 'flags_off_threshold': flag_total,
-           'flag_mismatches': flag_mismatch, 'stats': {}}
+           'flag_mismatches': flag_mismatch, 'stats': {}, 'policy': 'random' if policy is None else type(policy).__name__,
+           'final_success': float(np.mean(oko)), 'schedule_env_steps': sched}
     for name, w in worst.items():
         e = np.concatenate(w)
         out['stats'][name] = {'max': float(e.max()), 'p99.9': float(np.percentile(e, 99.9)), 'p99': float(np.percentile(e, 99)),
@@ -100,7 +110,15 @@ if __name__ == '__main__':
     task = sys.argv[1] if len(sys.argv) > 1 else 'push'
     N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-    dev = not (len(sys.argv) > 4 and sys.argv[4] == 'f32')
+    dev = 'f32' not in sys.argv[4:]
     kw = {'num_block': {'block_stack': 4, 'block_rearrange': 3, 'chest_push': 2, 'chest_pick_and_place': 2}.get(task, 4)} if task.startswith(('block', 'chest')) else {}
-    r = run(task, N, T, kw, device=dev)
+    pol = None
+    if 'scripted' in sys.argv[4:]:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import scripted_policies
+        if task.startswith('chest'):
+            kw['num_block'] = 1
+        kw['max_episode_steps'] = T
+        pol = scripted_policies.make_policy(task, N, **({'num_block': kw['num_block']} if 'num_block' in kw else {}))
+    r = run(task, N, T, kw, device=dev, policy=pol, keep_schedule=dev)
     print(json.dumps(r))
