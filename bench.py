@@ -5,13 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # or is launched per rank
 
 One "step" = one batched env.step() over 4096 envs per GPU (BASELINE.json configs[1]: task='reach', 4096 vectorised
-envs, random policy, state obs), actions pre-generated and resident in HBM, episodes reset every max_episode_steps=50
-steps inside the timed region, and -- for N > 1 -- one RCCL all-gather of the packed observation shard per step.  W
-untimed warm-up steps, then EXACTLY K timed steps between barrier + stream sync; the slowest rank's time counts; rank 0
-prints ONE JSON line.  `value` is that K-step window; because a short window early in an episode flatters the number
-(no env has walked down to the table yet), the line also says which episode steps the window covered and carries
-`full_episodes` (the same loop over whole episodes) and `host_api` (numpy in / numpy out through env.step(), PCIe
-inclusive) as secondary fields -- never as `value`.
+envs, random policy, state obs), actions pre-generated and resident in HBM, and -- for N > 1 -- one RCCL all-gather of
+the packed observation shard per step.  Episodes are max_episode_steps=50 long and their phases are STAGGERED, as in an
+RL loop that resets each env when its own episode ends: env i starts at phase i mod 50 (an untimed pre-roll of one
+episode brings the batch there) and every batched step is followed by the masked reset of the 1/50 of the batch whose
+episode just ended -- inside the timed region.  Any window of K steps therefore sees every episode phase in the same
+proportion, and `value` no longer depends on where in an episode a short window falls (`--lockstep` restores the old
+all-envs-in-phase loop).  W untimed warm-up steps, then EXACTLY K timed steps between barrier + stream sync; the slowest
+rank's time counts; rank 0 prints ONE JSON line.  Secondary fields, never `value`: `full_episodes` (the same loop over
+two whole episodes) and `host_api` (numpy in / numpy out through env.step(), PCIe inclusive).
 
 The env is the C-ABI HIP library (ctypes).  No PyTorch anywhere: the ranks rendezvous over stdlib TCP
 (pybullet_multigoal_gym_amd.distributed.Rendezvous) for the 128-byte RCCL id, the barriers and the max over ranks.
@@ -46,6 +48,25 @@ def _committed(pattern):
     return sorted(glob.glob(os.path.join(ROOT, 'profiles', pattern)), reverse=True)   # newest round tag first
 
 
+def kernel_source_hash():
+    """sha256 over the sources libpmg_hip.so is built from (csrc/*, include/*.h, the Makefile with its flags): what ties a
+    committed counter pass to the kernels that are running.  The .so itself is not hashed: hipcc stamps build metadata
+    into it, so a rebuild from the same sources differs byte-wise."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc', '*.[hc]*')) +
+                   glob.glob(os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc', '*.inc')) +
+                   glob.glob(os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc', 'Makefile')) +
+                   glob.glob(os.path.join(ROOT, 'include', '*.h')))
+    for f in files:
+        if f.endswith(('.so', '.o')):
+            continue
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic(task, n_envs):
     """HBM bytes per batched step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs of this same command, KiB -> bytes, with the calibration factors of the
@@ -55,20 +76,22 @@ def committed_traffic(task, n_envs):
         try:
             d = json.load(open(f))
             if d.get('task') == task and d.get('envs_per_gpu') == n_envs:
-                return float(d['hbm_bytes_per_launch'])
+                return float(d['hbm_bytes_per_launch']), d.get('kernel_source_sha16'), os.path.basename(f)
         except Exception:
             continue
-    return None
+    return None, None, None
 
 
 def committed_counters(task, n_envs):
     """Per-step instruction counters of the committed PMC pass (profiles/*_pmc_summary.json), or {}."""
     for f in _committed('*_%s%d_pmc_summary.json' % (task, n_envs)):
         try:
-            return {k: float(v['mean_per_launch']) for k, v in json.load(open(f)).items()}
+            d = json.load(open(f))
+            stamp = d.pop('_stamp', {})
+            return {k: float(v['mean_per_launch']) for k, v in d.items()}, stamp.get('kernel_source_sha16'), os.path.basename(f)
         except Exception:
             continue
-    return {}
+    return {}, None, None
 
 
 def usable_cores():
@@ -141,6 +164,7 @@ def main():
     ap.add_argument('--episode-steps', type=int, default=50)
     ap.add_argument('--dense-reward', action='store_true', help='binary_reward=False (BASELINE.json configs[3] runs both)')
     ap.add_argument('--lib', default=None, help='alternative libpmg_hip.so build (kernel A/B experiments)')
+    ap.add_argument('--lockstep', action='store_true', help='all envs in the same episode phase, one full reset every episode-steps steps (the round-1/2 loop)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -184,17 +208,29 @@ def main():
             host_gather = True
     # synthetic random policy: a table of batches of U(-1,1) float32 actions, resident in HBM
     E = 0 if args.no_extras else 2 * T                     # extra whole episodes for the secondary measurement
-    table = np.random.RandomState(12345 + rank).uniform(-1, 1, (K + W + E, N, A)).astype(np.float32)
+    stagger = not args.lockstep
+    P = T if stagger else 0                                # untimed pre-roll: one episode, brings env i to phase i mod T
+    table = np.random.RandomState(12345 + rank).uniform(-1, 1, (P + K + W + E, N, A)).astype(np.float32)
     actions = h.device_alloc(table.nbytes)
     h.upload(actions, table)
     stride = N * A * 4
     mine = np.empty((N, env.dims.packed_dim), np.float32) if host_gather else None
+    masks = None
+    if stagger:
+        # masks[p][i] = 1 where (i + p) % T == 0: after batched step t the envs with (global index + t + 1) % T == 0 have
+        # finished their episode (TimeLimit: done) and are reset before the next step, N/T of them every step
+        gi = rank * N + np.arange(N)
+        m = np.stack([((gi + p) % T == 0) for p in range(T)]).astype(np.uint8)
+        masks = h.device_alloc(m.nbytes)
+        h.upload(masks, m)
 
     def run(first, count, phase0=0):
         for t in range(first, first + count):
-            if (t - phase0) % T == 0:
+            if not stagger and (t - phase0) % T == 0:
                 h.reset_device(None)
             h.step_device(actions + t * stride)
+            if stagger:
+                h.reset_device(masks + ((t + 1) % T) * N)
             if gathered is not None:
                 h.allgather_packed(gathered)
             elif host_gather:
@@ -216,22 +252,57 @@ def main():
         el = time.perf_counter() - t0
         return rdv.max(el) if multi else el
 
-    run(0, W)
-    el = timed(W, K)
+    if stagger:
+        h.reset_device(None)
+    run(0, P + W)
+    el_local = None
+
+    def timed_keep(first, count, phase0=0):
+        nonlocal el_local
+        fence()
+        h.timing_reset()
+        t0 = time.perf_counter()
+        run(first, count, phase0)
+        h.sync()
+        el_local = time.perf_counter() - t0                # this rank's own clock, before it waits for the others
+        fence()
+        el_all = time.perf_counter() - t0
+        return rdv.max(el_all) if multi else el_all
+
+    el = timed_keep(P + W, K)
     kmin, kernel_ms, kmax, launches = h.timing_stats()
+    per_rank = None
+    if multi:
+        # diagnosability of the N > 1 run: every rank's own wall clock, step-kernel average and all-gather events
+        cavg, cmax, cn = h.comm_timing() if gathered is not None else (0.0, 0.0, 0)
+        rows = rdv.allgather(np.array([el_local / K * 1e3, kernel_ms, kmax, cavg, cmax, float(cn)], np.float64))
+        if rank == 0:
+            rows = np.asarray(rows).reshape(world, 6)
+            per_rank = {'ms_per_step': [round(float(x), 4) for x in rows[:, 0]],
+                        'kernel_ms': [round(float(x), 4) for x in rows[:, 1]],
+                        'kernel_ms_max': [round(float(x), 4) for x in rows[:, 2]],
+                        'allgather_ms': [round(float(x), 4) for x in rows[:, 3]],
+                        'allgather_ms_max': [round(float(x), 4) for x in rows[:, 4]],
+                        'allgather_launches': [int(x) for x in rows[:, 5]],
+                        'rank_spread_ms': round(float(rows[:, 0].max() - rows[:, 0].min()), 4),
+                        'slowest_rank': int(rows[:, 0].argmax()),
+                        'note': 'ms_per_step: each rank\'s own clock over its K steps (value uses the slowest rank incl. the '
+                                'closing barrier); allgather_ms: HIP events around ncclAllGather on the rank\'s stream, i.e. '
+                                'transfer + the wait for the slowest peer; expected transfer for %d B per rank over xGMI: '
+                                '%.1f us at 50 GB/s' % (N * env.dims.packed_dim * 4, (world - 1) * N * env.dims.packed_dim * 4 / 50e9 * 1e6)}
     full = None
     if E:
-        el_full = timed(K + W, E, phase0=K + W)            # starts with a reset: exactly two whole episodes
+        el_full = timed(P + K + W, E, phase0=P + K + W)    # lockstep: starts with a reset; exactly two whole episodes
         fmin, favg, fmax, fl = h.timing_stats()
         full = {'value': world * N * E / el_full, 'unit': 'env-steps/s', 'steps': E, 'ms_per_step': el_full / E * 1e3,
                 'kernel_ms': {'min': fmin, 'avg': favg, 'max': fmax},
-                'note': 'the same loop over %d whole %d-step episodes (every episode phase weighted equally)' % (E // T, T)}
+                'note': 'the same loop over %d more steps = %d whole %d-step episodes (every episode phase weighted equally)' % (E, E // T, T)}
     host = None
     if E and world == 1:
         # what a numpy-only RL loop gets: env.step(numpy actions) -> numpy observations (H2D actions, kernel, D2H packed
         # rows, unpack); one whole episode.  Never `value`.
         hs = T
-        acts = table[:hs]
+        acts = table[P:P + hs]
         env.reset()
         t0 = time.perf_counter()
         for t in range(hs):
@@ -245,7 +316,9 @@ def main():
         value = world * N * K / el
         algo = ALGO_BYTES[args.task] * N
         achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        first_ep = W % T
+        src_hash = kernel_source_hash()
+        traffic, traffic_src, traffic_file = committed_traffic(args.task, N)
+        cnt, cnt_src, cnt_file = committed_counters(args.task, N)
         out = {
             'metric': 'env-steps/sec at N_envs=4096/GPU, KukaReach' if args.task == 'reach' and N == 4096
                       else 'env-steps/sec at N_envs=%d/GPU, %s' % (N, args.task),
@@ -253,14 +326,23 @@ def main():
             'ms_per_step': el / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': "task='%s', %d vectorised envs/GPU, random policy U(-1,1), state obs, %s reward, "
-                                   'reset every %d steps, 100 substeps/env-step'
-                                   % (args.task, N, 'dense' if args.dense_reward else 'binary', T),
+                                   '%d-step episodes (%s), 100 substeps/env-step'
+                                   % (args.task, N, 'dense' if args.dense_reward else 'binary', T,
+                                      'phases staggered: env i at phase i mod %d, masked reset of 1/%d of the batch after every step, inside the timed region' % (T, T)
+                                      if stagger else 'lockstep: one reset of the whole batch every %d steps' % T),
                        'global_envs': world * N, 'parallelism': 'env-shard x%d; %s' % (world, collective),
-                       'window': 'timed steps = episode steps %d..%d of %d-step episodes%s' % (
-                           first_ep, first_ep + K - 1, T, '' if K >= T else
-                           ' (shorter than an episode: see full_episodes for the phase-weighted rate)')},
+                       'window': ('every episode phase is present in every batched step (staggered), so a %d-step window is '
+                                  'representative; %d masked resets inside it' % (K, K)) if stagger else
+                                 'timed steps = episode steps %d..%d of %d-step episodes%s' % (
+                                     W % T, W % T + K - 1, T, '' if K >= T else
+                                     ' (shorter than an episode: see full_episodes for the phase-weighted rate)')},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': committed_traffic(args.task, N),
+                         'frac': achieved / HBM_PEAK_GBS,
+                         # counters come from a committed rocprofv3 --pmc pass: reported only when that pass profiled
+                         # THESE kernel sources (sha256 of csrc/ + include/ stamped into the pass), else null
+                         'traffic': traffic if (traffic_src == src_hash) else None,
+                         'traffic_source': {'file': traffic_file, 'profiled_kernel_sources': traffic_src, 'running_kernel_sources': src_hash,
+                                            'match': traffic_src == src_hash},
                          'kernel': 'pmg_k_step_reach (+ pmg_k_redo)' if args.task == 'reach' else 'pmg_k_step<NB,MAXC,CYL> family',
                          'kernel_ms': kernel_ms, 'kernel_ms_min': kmin, 'kernel_ms_max': kmax, 'launches': launches,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES[args.task],
@@ -269,8 +351,7 @@ def main():
                                  'issues ~1 instruction / 4.3 cycles; a batched step lasts as long as its slowest wavefront = '
                                  'an env with finger-table contacts: kernel_ms_max vs kernel_ms_min); see roofline.valu'},
         }
-        cnt = committed_counters(args.task, N)
-        if cnt.get('SQ_INSTS_VALU') and kernel_ms > 0:
+        if cnt.get('SQ_INSTS_VALU') and kernel_ms > 0 and cnt_src == src_hash:
             vi = cnt['SQ_INSTS_VALU']
             v = {'insts_per_launch': vi, 'peak_insts_per_s': VALU_PEAK_INSTS, 'util': vi / (kernel_ms * 1e-3) / VALU_PEAK_INSTS,
                  'source': 'SQ_INSTS_VALU of the committed rocprofv3 --pmc pass over the live kernel time; peak = 1024 SIMD-32 '
@@ -281,7 +362,11 @@ def main():
                 v.update(fp32_flop_per_launch=flops, achieved_tflops=flops / (kernel_ms * 1e-3) / 1e12, peak_tflops=FP32_PEAK_TFLOPS,
                          flop_frac=flops / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                          flop_source='64 x (ADD_F32 + MUL_F32 + 2 FMA_F32 + TRANS_F32) wave-instruction counters: an upper bound, idle lanes included')
+            v['counter_file'] = cnt_file
+            v['profiled_kernel_sources'] = cnt_src
             out['roofline']['valu'] = v
+        if per_rank is not None:
+            out['per_rank'] = per_rank
         if full is not None:
             out['full_episodes'] = full
         if host is not None:
@@ -293,6 +378,8 @@ def main():
         assert 'torch' not in sys.modules, 'torch was imported by a bench rank'
         print('no torch in rank 0 (%d modules loaded)' % len(sys.modules), file=sys.stderr, flush=True)
     h.device_free(actions)
+    if masks is not None:
+        h.device_free(masks)
     if gathered is not None:
         h.device_free(gathered)
     env.close()

@@ -202,6 +202,9 @@ int pmg_timing_read(pmg_env* env, double* avg_step_kernel_ms, int64_t* launches)
 /* the same launches: shortest / average / longest (any pointer may be NULL).  A batched step lasts as long as its slowest
  * wavefront, so the spread shows how often envs with finger x table / object contacts were in the batch. */
 int pmg_timing_stats(pmg_env* env, double* min_ms, double* avg_ms, double* max_ms, int64_t* launches);
+/* HIP events around every pmg_allgather_packed since the last pmg_timing_reset(): average / longest ms on this rank's
+ * stream (it includes the wait for the slowest peer to arrive) and the count (any pointer may be NULL). */
+int pmg_comm_timing(pmg_env* env, double* avg_ms, double* max_ms, int64_t* launches);
 
 /* The per-env MT19937 streams (625 words each: state + cursor), [N, 625] uint32: with pmg_get_state / pmg_set_state a
  * checkpoint that resumes with the SAME future goals, orders and curriculum draws (no reference equivalent).  The

@@ -49,7 +49,7 @@ class PmgLibrary:
                'pmg_compute_reward', 'pmg_compute_reward_device', 'pmg_get_state', 'pmg_set_state', 'pmg_set_goal',
                'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_read',
                'pmg_device_alloc', 'pmg_device_free', 'pmg_upload', 'pmg_download',
-               'pmg_set_sub_goal', 'pmg_curriculum_update', 'pmg_curriculum_read', 'pmg_timing_stats', 'pmg_get_rng', 'pmg_set_rng']
+               'pmg_set_sub_goal', 'pmg_curriculum_update', 'pmg_curriculum_read', 'pmg_timing_stats', 'pmg_get_rng', 'pmg_set_rng', 'pmg_comm_timing']
 
     def __init__(self, path=None):
         self.path = path or DEFAULT_LIBRARY
@@ -273,6 +273,12 @@ class PmgHandle:
     def comm_init(self, rank, nranks, uid):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         self._check(self.L.lib.pmg_comm_init(self.h, C.c_int(rank), C.c_int(nranks), buf))
+
+    def comm_timing(self):
+        """(avg, max) ms of the all-gathers since timing_reset() on this rank's stream, and their count."""
+        avg, hi, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.L.lib.pmg_comm_timing(self.h, C.byref(avg), C.byref(hi), C.byref(n)))
+        return avg.value, hi.value, n.value
 
     def allgather_packed(self, d_out_ptr):
         self._check(self.L.lib.pmg_allgather_packed(self.h, C.c_void_p(d_out_ptr)))

@@ -109,6 +109,10 @@ struct pmg_env {
     float* d_rw_ag = nullptr; float* d_rw_dg = nullptr; float* d_rw_r = nullptr; unsigned char* d_rw_ok = nullptr;
     long long rw_cap = 0;
     hipEvent_t ev_a[EVENT_POOL], ev_b[EVENT_POOL];
+    hipEvent_t cv_a[EVENT_POOL], cv_b[EVENT_POOL];   /* the same around every all-gather */
+    int cv_n = 0;
+    double cv_ms = 0.0, cv_max = 0.0;
+    long long cv_launches = 0;
     int ev_n = 0;
     double ev_ms = 0.0, ev_min = 0.0, ev_max = 0.0;
     long long ev_launches = 0;
@@ -282,6 +286,19 @@ void drain_events(pmg_env* e)
     e->ev_n = 0;
 }
 
+void drain_comm_events(pmg_env* e)
+{
+    for (int i = 0; i < e->cv_n; i++) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(e->cv_b[i]);
+        if (hipEventElapsedTime(&ms, e->cv_a[i], e->cv_b[i]) == hipSuccess) {
+            if (ms > e->cv_max) e->cv_max = ms;
+            e->cv_ms += ms; e->cv_launches++;
+        }
+    }
+    e->cv_n = 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -334,6 +351,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipHostMalloc((void**)&e->h_packed, N * dims.packed_dim * sizeof(float)));
     CREATE_TRY(hipHostMalloc((void**)&e->h_actions, N * dims.action_dim * sizeof(float)));
     for (int i = 0; i < EVENT_POOL; i++) { CREATE_TRY(hipEventCreate(&e->ev_a[i])); CREATE_TRY(hipEventCreate(&e->ev_b[i])); }
+    for (int i = 0; i < EVENT_POOL; i++) { CREATE_TRY(hipEventCreate(&e->cv_a[i])); CREATE_TRY(hipEventCreate(&e->cv_b[i])); }
     /* initial state: rest pose kuka.py:27, blocks parked below the floor */
     {
         static const float rest0[7] = {0.f, -0.5592432f, 0.f, 1.733180f, 0.f, -0.8501557f, 0.f};
@@ -377,6 +395,7 @@ void pmg_destroy(pmg_env* e)
     if (e->h_packed) (void)hipHostFree(e->h_packed);
     if (e->h_actions) (void)hipHostFree(e->h_actions);
     for (int i = 0; i < EVENT_POOL; i++) { if (e->ev_a[i]) (void)hipEventDestroy(e->ev_a[i]); if (e->ev_b[i]) (void)hipEventDestroy(e->ev_b[i]); }
+    for (int i = 0; i < EVENT_POOL; i++) { if (e->cv_a[i]) (void)hipEventDestroy(e->cv_a[i]); if (e->cv_b[i]) (void)hipEventDestroy(e->cv_b[i]); }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
@@ -696,8 +715,12 @@ int pmg_allgather_packed(pmg_env* e, float* d_gathered)
     if (!e->comm) return fail(e, PMG_E_STATE, "pmg_allgather_packed: pmg_comm_init was not called");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     size_t count = (size_t)e->dims.num_envs * e->dims.packed_dim;
+    if (e->cv_n == EVENT_POOL) drain_comm_events(e);
+    int i = e->cv_n++;
+    HIP_TRY(e, hipEventRecord(e->cv_a[i], e->stream));
     ncclResult_t rc = ncclAllGather(e->P.out, d_gathered, count, ncclFloat, e->comm, e->stream);
     if (rc != ncclSuccess) return fail(e, PMG_E_COMM, "ncclAllGather -> %s", ncclGetErrorString(rc));
+    HIP_TRY(e, hipEventRecord(e->cv_b[i], e->stream));
     return PMG_OK;
 }
 
@@ -741,6 +764,9 @@ int pmg_timing_reset(pmg_env* e)
     e->ev_n = 0;
     e->ev_ms = e->ev_min = e->ev_max = 0.0;
     e->ev_launches = 0;
+    e->cv_n = 0;
+    e->cv_ms = e->cv_max = 0.0;
+    e->cv_launches = 0;
     return PMG_OK;
 }
 int pmg_timing_stats(pmg_env* e, double* min_ms, double* avg_ms, double* max_ms, int64_t* launches)
@@ -753,6 +779,17 @@ int pmg_timing_stats(pmg_env* e, double* min_ms, double* avg_ms, double* max_ms,
     if (max_ms) *max_ms = e->ev_max;
     if (avg_ms) *avg_ms = e->ev_launches ? e->ev_ms / (double)e->ev_launches : 0.0;
     if (launches) *launches = e->ev_launches;
+    return PMG_OK;
+}
+int pmg_comm_timing(pmg_env* e, double* avg_ms, double* max_ms, int64_t* launches)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    drain_comm_events(e);
+    if (avg_ms) *avg_ms = e->cv_launches ? e->cv_ms / (double)e->cv_launches : 0.0;
+    if (max_ms) *max_ms = e->cv_max;
+    if (launches) *launches = e->cv_launches;
     return PMG_OK;
 }
 int pmg_timing_read(pmg_env* e, double* avg_ms, int64_t* launches)

@@ -146,7 +146,7 @@ def replay(fx, env, tol_static=2e-6, tol_traj=2e-6, tol_vel=None, traj_steps=Non
     thr = fx['make_kwargs'].get('distance_threshold', 0.05)
     binary = fx['make_kwargs'].get('binary_reward', True)
     tol_vel = tol_traj if tol_vel is None else tol_vel
-    worst = dict(static=0.0, traj=0.0)
+    worst = dict(static=0.0, traj=0.0, obs=0.0)
     since_reset = 0
     died = False
     for i, ev in enumerate(fx['events']):
@@ -186,9 +186,10 @@ def replay(fx, env, tol_static=2e-6, tol_traj=2e-6, tol_vel=None, traj_steps=Non
             assert bool(d) == out['done'], (tag, d, out['done'])
             check_traj = traj_steps is None or since_reset <= traj_steps
             if check_traj:
-                for k in KEYS:
+                for k in KEYS:      # 'observation' holds velocities too: its own bar and its own worst
                     t = tol_vel if k == 'observation' else tol_traj
-                    worst['traj'] = max(worst['traj'], _cmp(tag + ' ' + k, o[k], out['obs'][k], t))
+                    w = 'obs' if k == 'observation' else 'traj'
+                    worst[w] = max(worst[w], _cmp(tag + ' ' + k, o[k], out['obs'][k], t))
                 dist = float(np.linalg.norm(np.asarray(out['obs']['achieved_goal']) - np.asarray(out['obs']['desired_goal'])))
                 if abs(dist - thr) > threshold_guard:
                     assert bool(ok) == out['goal_achieved'], (tag, ok, out['goal_achieved'], dist)

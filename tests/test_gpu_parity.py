@@ -13,6 +13,9 @@ OBS_TOL = 2e-4
 STATE_TOL = 5e-4
 
 
+JOINT_OUTLIERS = 2
+
+
 def _pair(task, N, **kw):
     env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, **kw)
     ora = oracle_lib.OracleEnv(task, N, seed_base=0, seed_stride=1, threads=8,
@@ -32,8 +35,10 @@ def test_reach_rollout_matches_oracle(built, joint_control):
     into the table, where the solver's own early-exit threshold (1e-7 on squared velocity changes,
     i.e. ~3e-4 m/s) is the parity floor, so the bound is the contact one."""
     N, T = 64, 50
-    OBS_TOL = 2e-4 if not joint_control else 2e-3
-    STATE_TOL = 5e-4 if not joint_control else 5e-2
+    # joint control: the maximum over the envs but for JOINT_OUTLIERS of the 64 (fingers scraping the table for a whole
+    # episode: stick / slip flips in float32); measured round 2: median 3.6e-7, p90 3.5e-6
+    OBS_TOL = 2e-4 if not joint_control else 1e-3
+    STATE_TOL = 5e-4 if not joint_control else 5e-3     # the state rows hold velocities too (solver early exit: ~3e-4 m/s)
     env, ora = _pair('reach', N, joint_control=joint_control)
     o, oo = env.reset(), ora.reset()
     assert np.array_equal(o['desired_goal'], oo['desired_goal'])
@@ -47,7 +52,7 @@ def test_reach_rollout_matches_oracle(built, joint_control):
         o, r, d, info = env.step(a)
         oo, ro, do, oko = ora.step(a)
         per_env = np.maximum(per_env, np.abs(o['observation'] - oo['observation']).max(1))
-        worst = float(per_env.max()) if not joint_control else float(np.percentile(per_env, 90))
+        worst = float(per_env.max()) if not joint_control else float(np.sort(per_env)[-1 - JOINT_OUTLIERS])
         assert np.array_equal(d, do)
         # reward may only differ where the distance sits on the threshold
         dist = np.linalg.norm(oo['achieved_goal'] - oo['desired_goal'], axis=-1)
@@ -56,7 +61,7 @@ def test_reach_rollout_matches_oracle(built, joint_control):
         assert np.array_equal(info['goal_achieved'][clear], oko[clear])
     assert worst < OBS_TOL, worst
     serr = np.abs(env.get_state() - ora.get_state()).max(1)
-    assert (serr.max() if not joint_control else np.percentile(serr, 90)) < STATE_TOL
+    assert (serr.max() if not joint_control else np.sort(serr)[-1 - JOINT_OUTLIERS]) < STATE_TOL
     assert np.median(per_env) < 2e-4
     assert d.all()
     env.close()
@@ -93,6 +98,19 @@ def test_compute_reward_batch(built):
                                      ('slide', {}), ('block_stack', {'num_block': 4}), ('block_rearrange', {'num_block': 3}),
                                      ('chest_push', {'num_block': 2}), ('chest_pick_and_place', {'num_block': 5, 'grip_informed_goal': True}),
                                      ('chest_push', {'num_block': 3, 'joint_control': True}), ('block_stack', {'num_block': 5, 'joint_control': True})])
+def _max_or_count(what, err, spread, bar=1e-3, extra=1):
+    """Bar on the MAXIMUM over the envs (BASELINE.json's 1e-3), with a count for the envs beyond it: a contact made or
+    missed one substep apart bifurcates a float32 rollout, so there may be as many such envs as the float32 build of the
+    ORACLE itself has against the float64 one on the same seeds and actions, plus `extra`; everybody else must be inside
+    the bar, and the typical env at float32 rounding (3 x the float32 oracle's median, at least 2e-5)."""
+    err, spread = np.asarray(err, np.float64), np.asarray(spread, np.float64)
+    n_dev, n_f32 = int((err > bar).sum()), int((spread > bar).sum())
+    print('%-40s max %.2e median %.2e beyond %.0e: %d   | float32 oracle: max %.2e median %.2e beyond: %d'
+          % (what, err.max(), np.median(err), bar, n_dev, spread.max(), np.median(spread), n_f32))
+    assert n_dev <= n_f32 + extra, (what, n_dev, n_f32, np.sort(err)[-4:])
+    assert np.median(err) <= max(3 * np.median(spread), 2e-5), (what, np.median(err), np.median(spread))
+
+
 def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task, kw):
     """Contact-rich rollouts are chaotic and the PGS early exit makes velocities only ~3e-4 exact, so
     the HIP path is held to the float64 oracle within a small multiple of the oracle's OWN
@@ -114,12 +132,12 @@ def test_contact_tasks_match_oracle_within_its_own_precision_spread(built, task,
         o, r, d, info = env.step(a)
         a64, r64, d64, ok64 = o64.step(a)
         a32, r32, d32, ok32 = o32.step(a)
-    G = env.dims.goal_dim
     err = np.abs(o['achieved_goal'] - a64['achieved_goal']).max(1)      # block positions
     spread = np.abs(a32['achieved_goal'] - a64['achieved_goal']).max(1)
-    assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4, (np.percentile(err, 90), np.percentile(spread, 90))
+    _max_or_count('%s blocks' % task, err, spread)
     tip_err = np.abs(o['observation'][:, :3] - a64['observation'][:, :3]).max(1)
-    assert np.percentile(tip_err, 90) < 1e-3
+    tip_spread = np.abs(a32['observation'][:, :3] - a64['observation'][:, :3]).max(1)
+    _max_or_count('%s tip' % task, tip_err, tip_spread)
     if kw.get('binary_reward', True):
         assert (r != r64).mean() <= 0.02      # teacher-forced: no flag differs off the threshold (tests/test_gpu_tail_parity.py); here one of 64 envs may sit ON it
     else:
@@ -156,7 +174,7 @@ def test_constructed_cylinder_contacts_match_oracle(built, scenario):
     # bar: the oracle's own float32-vs-float64 spread on the same scenario (solver early-exit floor)
     for cols in (slice(0, 9), slice(64, 67)):
         err, spread = np.abs(se[:, cols] - so[:, cols]).max(1), np.abs(s32[:, cols] - so[:, cols]).max(1)
-        assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4, (cols, np.percentile(err, 90), np.percentile(spread, 90))
+        _max_or_count('%s %s' % (scenario, cols), err, spread)
     if scenario == 'slide_push':
         assert (so[:, 65] > 0.055).all() and np.abs(so[:, 66] - 0.170).max() < 1e-3   # pushed along +y, still on the table
     else:
@@ -195,9 +213,9 @@ def test_constructed_chest_contacts_match_oracle(built, task):
         a32, r32, _, _ = o32.step(a)
     err = np.abs(o['achieved_goal'] - a64['achieved_goal']).max(1)        # door joint + block positions
     spread = np.abs(a32['achieved_goal'] - a64['achieved_goal']).max(1)
-    assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4, (np.percentile(err, 90), np.percentile(spread, 90))
+    _max_or_count('%s constructed, door + blocks' % task, err, spread)
     tip_err = np.abs(o['observation'][:, :3] - a64['observation'][:, :3]).max(1)
-    assert np.percentile(tip_err, 90) < 1e-3
+    _max_or_count('%s constructed, tip' % task, tip_err, np.abs(a32['observation'][:, :3] - a64['observation'][:, :3]).max(1))
     so = ora.get_state()
     assert (so[:, 64] > -0.695).all() and (so[:, 64] < -0.6).all() and np.abs(so[:, 66] - 0.175).max() < 2e-3  # kept in by the walls
     if pnp:
@@ -228,7 +246,7 @@ def test_finger_opens_the_chest_door_by_its_handle(built):
     assert (q > 0.1).all()                                          # every env opened its door
     err = np.abs(o['achieved_goal'] - a64['achieved_goal']).max(1)
     spread = np.abs(a32['achieved_goal'] - a64['achieved_goal']).max(1)
-    assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4, (np.percentile(err, 90), np.percentile(spread, 90))
+    _max_or_count('door opened by its handle', err, spread)
     assert np.array_equal(env.get_state()[:, 50], ora.get_state()[:, 50])   # the same envs latched the motor
     env.close()
 
@@ -407,7 +425,8 @@ def test_row_packed_object_overflow_goes_through_redo(built):
     se, so, s32 = env.get_state(), ora.get_state(), o32.get_state()
     for cols in (slice(0, 9), slice(64, 67)):
         err, spread = np.abs(se[:, cols] - so[:, cols]).max(1), np.abs(s32[:, cols] - so[:, cols]).max(1)
-        assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4 and err[bad].max() < 3 * spread[bad].max() + 1e-3
+        _max_or_count('redo_obj %s' % cols, err, spread)
+        assert err[bad].max() < 3 * spread[bad].max() + 1e-3
     env.close()
 
 
@@ -591,7 +610,11 @@ def test_fast_paths_agree_with_one_env_per_wavefront(built, task, kw):
         assert tip.max() < 5e-5
         assert (rf != rr).mean() < 0.01 if kw.get('binary_reward', True) else np.abs(rf - rr).max() < 1e-4   # a distance may sit on the threshold
     else:
-        assert np.percentile(tip, 90) < 5e-4 and np.percentile(ag, 90) < 1e-3, (np.percentile(tip, 90), np.percentile(ag, 90))
+        # two float32 summation orders of the same algorithm over 12 chaotic contact steps: a count on the envs beyond 1e-3
+        print('%s fast paths vs one-env-per-wavefront: tip max %.2e beyond 1e-3: %d; objects max %.2e beyond 1e-3: %d of %d'
+              % (task, tip.max(), (tip > 1e-3).sum(), ag.max(), (ag > 1e-3).sum(), N))
+        assert (tip > 1e-3).mean() <= 0.03 and (ag > 1e-3).mean() <= 0.05, ((tip > 1e-3).mean(), (ag > 1e-3).mean())
+        assert np.median(tip) < 2e-5 and np.median(ag) < 2e-5, (np.median(tip), np.median(ag))
         assert (inf['goal_achieved'] != inr['goal_achieved']).mean() < 0.02
     fast.close(), ref.close()
 
@@ -624,7 +647,8 @@ def test_small_contact_store_overflow_goes_through_redo_multi(built):
     se, so, s32 = env.get_state(), ora.get_state(), o32.get_state()
     pos = [c for b in range(nb) for c in range(64 + 13 * b, 67 + 13 * b)]
     err, spread = np.abs(se[:, pos] - so[:, pos]).max(1), np.abs(s32[:, pos] - so[:, pos]).max(1)
-    assert np.percentile(err, 90) <= 3 * np.percentile(spread, 90) + 2e-4 and err[bad].max() < 3 * spread[bad].max() + 1e-3
+    _max_or_count('redo_multi blocks', err, spread)
+    assert err[bad].max() < 3 * spread[bad].max() + 1e-3
     env.close()
 
 

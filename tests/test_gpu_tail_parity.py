@@ -31,8 +31,8 @@ ABSOLUTE = {
     'reach': {'tip_pos': (2e-5, 0), 'q_arm': (1e-4, 0), 'q_finger': (1e-4, 0)},                          # 5.9e-6, 3.0e-5, 2.0e-5
     'push': {'tip_pos': (1e-4, 0), 'block_pos': (5e-5, 0), 'q_arm': (1e-3, 10), 'q_finger': (2e-4, 0)},   # 1.5e-5, 6.4e-6, 2.0e-4 (3), 5.2e-5
     'pick_and_place': {'tip_pos': (1e-4, 0), 'block_pos': (1e-4, 0), 'q_arm': (3e-4, 0)},               # 2.2e-5, 2.7e-5, 5.9e-5
-    'block_stack': {'tip_pos': (2e-3, 10), 'block_pos': (3e-3, 12), 'q_arm': (2e-3, 10)},               # 3.4e-4 (3), 6.1e-4 (4), 4.1e-4 (3)
-    'block_rearrange': {'tip_pos': (2e-3, 10), 'block_pos': (1e-3, 20), 'q_arm': (3e-3, 20)},           # 2.6e-4 (2), 2.5e-4 (6), 7.5e-4 (6)
+    'block_stack': {'tip_pos': (1e-3, 10), 'block_pos': (1e-3, 12), 'q_arm': (1e-3, 10)},               # 3.4e-4 (3), 6.1e-4 (4), 4.1e-4 (3)
+    'block_rearrange': {'tip_pos': (1e-3, 10), 'block_pos': (1e-3, 20), 'q_arm': (1e-3, 20)},           # 2.6e-4 (2), 2.5e-4 (6), 7.5e-4 (6)
 }
 RELATIVE = ['slide', 'chest_push', 'chest_pick_and_place']
 

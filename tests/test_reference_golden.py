@@ -84,22 +84,38 @@ def test_emulated_kernels_reproduce_reference_session(built, emu_library, name):
     env.close()
 
 
-# float32 device vs the float64 physics under the fixtures: resets / goals / curricula / sub-goals to 2e-5 (positions of
-# a reset are IK solutions), trajectories at the bars of DESIGN.md section 5 over the first steps after each reset
-# measured (round 2): reach 2.5e-7 over whole episodes; contact tasks 4.6e-4 within six steps of a reset
-GPU_BARS = {'reach': dict(tol_traj=2e-5, tol_vel=1e-3, traj_steps=None)}     # velocities: 2.2e-4 with joint control (fingers on the table)
-GPU_DEFAULT = dict(tol_traj=1e-3, tol_vel=5e-3, traj_steps=6)
+# float32 device vs the float64 physics under the fixtures, over WHOLE episodes: resets / goals / curricula / sub-goals to
+# 2e-5 (positions of a reset are IK solutions); trajectories at BASELINE.json's 1e-3 (reach: 2e-5) -- unless the float32
+# build of the ORACLE itself, replaying the same session, strays further from the float64 fixture than 3e-4: that session
+# then contains a bifurcation in float32 arithmetic (a contact made or missed one substep apart) and the device is held to
+# twice the float32 oracle's own deviation instead.  Measured (round 3) next to GPU_BARS.
+GPU_BARS = {'reach': dict(tol_traj=2e-5, tol_vel=1e-3)}     # 2.5e-7; velocities 2.2e-4 with joint control (fingers on the table)
+GPU_DEFAULT = dict(tol_traj=1e-3, tol_vel=5e-3)
+
+
+def _float32_floor(fx):
+    env = R.OracleAdapter(fx, f32=True)
+    try:
+        return R.replay(fx, env, tol_static=1e9, tol_traj=1e9, tol_vel=1e9, threshold_guard=1e9, check_internal=False)
+    finally:
+        env.close()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('path', PATHS, ids=NAMES)
 def test_hip_reproduces_reference_session(built, hip_library, path):
     fx = R.load(path)
+    bars = dict(GPU_BARS.get(fx['task'], GPU_DEFAULT))
+    floor = _float32_floor(fx)
+    guard = 2e-3
+    if floor['traj'] > 3e-4 or floor['obs'] > 1.5e-3:      # bifurcation in float32 itself (see above)
+        bars['tol_traj'] = max(bars['tol_traj'], 2 * floor['traj'])
+        bars['tol_vel'] = max(bars['tol_vel'], 2 * floor['obs'])
+        guard = max(guard, 2 * floor['traj'])
     env = R.ProductAdapter(fx, library=hip_library)
-    bars = GPU_BARS.get(fx['task'], GPU_DEFAULT)
-    worst = R.replay(fx, env, tol_static=2e-5, threshold_guard=2e-3, **bars)
+    worst = R.replay(fx, env, tol_static=2e-5, threshold_guard=guard, traj_steps=None, **bars)
     env.close()
-    print('worst', os.path.basename(path), worst)
+    print('worst', os.path.basename(path), worst, 'float32 oracle floor', floor, 'bars', bars)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
