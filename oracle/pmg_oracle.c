@@ -49,11 +49,15 @@ typedef double real;
 /* [BULLET-PRIOR] choices, switchable (oracle only; the product compiles the defaults in).  With no PyBullet to ask,
  * each of these was settled from Bullet 3.0.x's published behaviour; pmgo_set_prior() lets the first real capture
  * (tools/gen_reference_fixtures.py --real) rank the alternatives instead of starting a debugging session.
- * NOT switchable, because they are structural: per-substep manifold regeneration (Bullet keeps a persistent
- * manifold) and the SAT cylinder pairs (Bullet: GJK/EPA).                                                     */
+ * Structural choices: the contact POINTS are regenerated every substep (Bullet refreshes a persistent 4-point manifold:
+ * for the box pairs of this scene btBoxBoxDetector re-adds the same clipped face points each substep, so the point sets
+ * agree while a contact persists); what a persistent manifold additionally carries -- the cached impulses -- is the
+ * `contact_warm_start` switch below.  The SAT cylinder pairs (Bullet: GJK/EPA) are cross-checked against an independent
+ * closest-point computation in tests/test_oracle_physics.py.                                                 */
 /* ------------------------------------------------------------------ */
 enum { PRIOR_MOTOR_IMPULSE_DT, PRIOR_LINK_DAMPING, PRIOR_JOINT_ERP, PRIOR_CONTACT_MARGIN, PRIOR_RESIDUAL_THRESHOLD,
-       PRIOR_IK_DAMPING, PRIOR_LINEAR_SLOP, PRIOR_WARM_START, PRIOR_DAMPING_PER_SUBSTEP, PRIOR_FRICTION_DIRS, PRIOR_N };
+       PRIOR_IK_DAMPING, PRIOR_LINEAR_SLOP, PRIOR_WARM_START, PRIOR_DAMPING_PER_SUBSTEP, PRIOR_FRICTION_DIRS,
+       PRIOR_SOLVER_ITERATIONS, PRIOR_CONTACT_WARM_START, PRIOR_N };
 static const char* const PRIOR_NAME[PRIOR_N] = {
     "motor_impulse_dt",     /* 0.04: max motor impulse = force x fixedTimeStep; 0.002 = force x substep */
     "link_damping",         /* 0.04: btMultiBody linear / angular damping; 0 = none */
@@ -64,10 +68,19 @@ static const char* const PRIOR_NAME[PRIOR_N] = {
     "linear_slop",          /* 1e-5 */
     "warm_start",           /* 0: non-contact rows start each substep from zero; f in (0, 1] = from f x last substep's impulses */
     "damping_per_substep",  /* 0: URDF joint damping latched once per stepSimulation; 1 = re-evaluated every substep */
-    "friction_dirs"         /* 2: two btPlaneSpace1 friction rows per contact; 1 = the first of them only */
+    "friction_dirs",        /* 2: two btPlaneSpace1 friction rows per contact; 1 = the first of them only */
+    "solver_iterations",    /* 5: base_env.py:37,218 numSolverIterations -- NOT a prior (the reference sets it); switchable
+                             * only to measure how much of a behaviour (creep of resting stacks / held blocks) is the
+                             * 5-iteration truncation of Gauss-Seidel */
+    "contact_warm_start"    /* 0: contact impulses start each substep from zero (what btMultiBodyConstraintSolver::
+                             * setupMultiBodyContactConstraint does: its warm-starting branch is compiled out for
+                             * multibody contacts, and every body PyBullet loads from a URDF is a btMultiBody);
+                             * f in (0, 1]: Bullet's persistent-manifold behaviour for rigid bodies -- a contact point that
+                             * persists (same pair, within the 0.02 breaking threshold of a cached point) starts from
+                             * f x its last normal impulse (btSequentialImpulseConstraintSolver: f = 0.85) */
 };
-static double G_PRIOR[PRIOR_N] = {0.04, 0.04, 0.2, 0.002, 1e-7, 0.5, 1e-5, 0.0, 0.0, 2.0};
-static const double PRIOR_DEFAULT[PRIOR_N] = {0.04, 0.04, 0.2, 0.002, 1e-7, 0.5, 1e-5, 0.0, 0.0, 2.0};
+static double G_PRIOR[PRIOR_N] = {0.04, 0.04, 0.2, 0.002, 1e-7, 0.5, 1e-5, 0.0, 0.0, 2.0, 5.0, 0.0};
+static const double PRIOR_DEFAULT[PRIOR_N] = {0.04, 0.04, 0.2, 0.002, 1e-7, 0.5, 1e-5, 0.0, 0.0, 2.0, 5.0, 0.0};
 
 /* ------------------------------------------------------------------ */
 /* constants                                    */
@@ -1312,6 +1325,9 @@ typedef struct {
     int cur_goal_step;       /* curriculum_goal_step */
     Block blk[NBMAX];
     real ws_m[NJ], ws_l[NJ]; /* last substep's motor / limit impulses (only read with the warm_start prior) */
+    int wsc_n;               /* last substep's contacts: pair, point on A, normal impulse (contact_warm_start prior only) */
+    int wsc_a[MAX_CONTACTS], wsc_b[MAX_CONTACTS];
+    real wsc_p[MAX_CONTACTS][3], wsc_imp[MAX_CONTACTS];
     mt19937 rng;
 } World;
 
@@ -1753,7 +1769,31 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
             r->applied = a0;
             for (int k = 0; k < NJ; k++) dqd[k] += r->dvr[k] * a0;
         }
-    for (int it = 0; it < SOLVER_ITERS; it++) {
+    if (G_PRIOR[PRIOR_CONTACT_WARM_START] != 0)   /* alternative prior: persistent contact points keep f x their impulse */
+        for (int c = 0; c < nc; c++) {
+            int best = -1;
+            real bd = (real)(0.02 * 0.02);            /* btPersistentManifold contact breaking threshold */
+            for (int j = 0; j < w->wsc_n; j++) {
+                if (w->wsc_a[j] != con[c].a || w->wsc_b[j] != con[c].b) continue;
+                real d[3];
+                v3sub(d, w->wsc_p[j], con[c].pa);
+                real dd = v3dot(d, d);
+                if (dd < bd) { bd = dd; best = j; }
+            }
+            if (best < 0) continue;
+            Row* r = &nrm[c];
+            real a0 = (real)G_PRIOR[PRIOR_CONTACT_WARM_START] * w->wsc_imp[best];
+            if (a0 <= 0) continue;
+            w->wsc_a[best] = -12345;                   /* one cached point feeds one new point */
+            r->applied = a0;
+            if (r->has_robot)
+                for (int d = 0; d < NJ; d++) dqd[d] += r->dvr[d] * a0;
+            ddoor += r->dd * a0;
+            for (int s2 = 0; s2 < 2; s2++)
+                if (r->blk[s2] >= 0) { v3axpy(dbl[r->blk[s2]], a0, r->dl[s2]); v3axpy(dba[r->blk[s2]], a0, r->da[s2]); }
+        }
+    const int solver_iters = (int)G_PRIOR[PRIOR_SOLVER_ITERATIONS];
+    for (int it = 0; it < solver_iters; it++) {
         real resid = 0;
         for (int j = 0; j < nn; j++) {
             int idx = (it & 1) ? j : nn - 1 - j;
@@ -1779,6 +1819,11 @@ static void substep(const pmgo_env* e, World* w, const real* tau)
             }
         }
         if (resid <= RESIDUAL_THRESHOLD) break;
+    }
+    w->wsc_n = nc;
+    for (int c = 0; c < nc; c++) {
+        w->wsc_a[c] = con[c].a; w->wsc_b[c] = con[c].b; w->wsc_imp[c] = nrm[c].applied;
+        v3cpy(w->wsc_p[c], con[c].pa);
     }
     for (int d = 0; d < NJ; d++) { w->ws_m[d] = 0; w->ws_l[d] = 0; }
     for (int j = 0; j < nn; j++) {
@@ -1902,6 +1947,7 @@ static void tip_state(const World* w, const Kin* k, real* pos, real* vel, real* 
 static void robot_reset(const pmgo_env* e, World* w)
 {
     real tq[4] = {(real)TOOL_QUAT[0], (real)TOOL_QUAT[1], (real)TOOL_QUAT[2], (real)TOOL_QUAT[3]};
+    w->wsc_n = 0;
     for (int d = 0; d < 7; d++) { w->q[d] = w->rest_pose[d]; w->qd[d] = 0; w->motor_maximp[d] = 0; } /* :158 + robot_bases.py:230-238 */
     real qo[NJ];
     ik_solve(w->q, e->tip_init, tq, IK_MAX_ITER, IK_THRESHOLD, qo);                                    /* :159 */
@@ -2536,6 +2582,7 @@ int pmgo_set_state(pmgo_env* e, const float* state)
         World* w = &e->w[i];
         const float* s = state + (size_t)i * S;
         for (int d = 0; d < 9; d++) { w->q[d] = s[d]; w->qd[d] = s[9 + d]; }
+        w->wsc_n = 0;
         for (int a = 0; a < 3; a++) w->ee_target[a] = s[18 + a];
         for (int d = 0; d < 7; d++) { w->joint_target[d] = s[21 + d]; w->rest_pose[d] = s[32 + d]; }
         w->grip_target = s[28]; w->elapsed = (int)s[29]; w->arm_enabled = (int)s[30]; w->reset_count = (int)s[31];

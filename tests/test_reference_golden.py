@@ -137,7 +137,8 @@ def test_oracle_matches_real_pybullet_capture(built, path):
 
 
 ALTERNATIVES = {'motor_impulse_dt': [0.04, 0.002], 'warm_start': [0.0, 0.85], 'link_damping': [0.04, 0.0],
-                'damping_per_substep': [0.0, 1.0], 'residual_threshold': [1e-7, 0.0], 'friction_dirs': [2.0, 1.0]}
+                'damping_per_substep': [0.0, 1.0], 'residual_threshold': [1e-7, 0.0], 'friction_dirs': [2.0, 1.0],
+                'contact_warm_start': [0.0, 0.85]}
 
 
 def rank_priors(fixtures, alternatives=None):
