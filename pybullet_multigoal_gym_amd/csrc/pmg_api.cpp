@@ -343,9 +343,13 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipMalloc((void**)&e->P.blocks, N * pmg::BLOCK_DIM * (nb ? nb : 1) * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.rng, N * 625 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
-    CREATE_TRY(hipMalloc((void**)&e->P.sched, (3 + 3 * N) * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&e->P.sched, (3 + 3 * N + 3 * ((N + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS)) * sizeof(int)));
     if (const char* pk = getenv("PMG_PACKED")) e->packed = atoi(pk) != 0;
-    if (N > (size_t)pmg::PLAN_MAX_TILES * 64) e->packed = 0; /* beyond the plan kernel's reach: one env per wavefront, identity order */
+    {   /* 1.5 wavefronts per SIMD of this device: how many one-env wavefronts the plan may add to a step */
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus <= 0) cus = 256;
+        e->P.wave_budget = 6 * cus;
+    }
     CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->d_mask, N));
     CREATE_TRY(hipHostMalloc((void**)&e->h_packed, N * dims.packed_dim * sizeof(float)));

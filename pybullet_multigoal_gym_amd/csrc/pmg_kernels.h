@@ -24,6 +24,7 @@ struct EnvParams {
                                           the door's joint position, velocity and motor latch live in goal[0..2] */
     double goals_per_curriculum;
     int adim, odim, pdim, gdim, packed;
+    int wave_budget;        /* 1.5 wavefronts per SIMD of THIS device (6 x CUs: 1536 on an MI355X): pmg_k_plan's promotion rule */
     float thr;
     float ee_lo[3], ee_hi[3];
     float table_c[3], table_h[3], table_mu;
@@ -38,7 +39,8 @@ struct EnvParams {
     unsigned* rng;   /* [N, 625] MT19937 state + index */
     float* out;      /* [N, packed]: obs | policy | ag | dg | reward | goal_achieved | done */
     int* sched;      /* [3 + 3N]: counts of {contact-prone, other} envs, the two env lists, then the redo count + list
-                        of the row-packed path (pmg_packed.h) */
+                        of the row-packed path (pmg_packed.h); behind it [3 x ceil(N / 1024)] per-workgroup class counts
+                        of the two-pass plan (batches beyond one plan workgroup) */
 #ifdef PMG_PROFILE
     long long* prof; /* [32] per-phase shader cycles of env 0 */
 #endif
@@ -201,7 +203,7 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
      * the batch AND the step then still fits 1.5 wavefronts per SIMD (1024 SIMDs; at 8192 envs the packed wavefronts
      * alone are two per SIMD and the extra one-env wavefronts cost more than they save: 1.74 -> 1.65 M) */
     const bool promote = PMG_FD_DIV > 0 && P.nb == 1 && !P.joint_control && n1 * PMG_FD_DIV <= P.n_envs &&
-                         n0all + n1 + ((n2all + 3) >> 2) <= 1536;
+                         n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget;
     for (int c = 0; c < chunks; c++) {
         int tile = c * waves + wave;
         int env = c * PLAN_THREADS + tid;
@@ -219,6 +221,64 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
         for (int t = 0; t < tiles; t++) { n0 += cnt0[t]; n2 += cnt2[t]; }
         P.sched[0] = promote ? n0 + n1 : n0;
         P.sched[1] = promote ? n2 : n1 + n2;
+        P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
+    }
+}
+/* Batches beyond one plan workgroup (65 536 envs): the same stable three-way partition in two passes over
+ * ceil(N / 1024) workgroups.  Pass 1 leaves every workgroup's class counts behind the schedule; pass 2 re-derives the
+ * classes (a few loads and compares per env), turns the counts of the workgroups before it into its bases and the
+ * grand totals into the promotion decision -- the SAME decision in every workgroup, so the lists come out exactly as
+ * the single-workgroup plan would write them -- and scatters. */
+__device__ __forceinline__ int* plan_wg_counts(const EnvParams& P) { return P.sched + 3 + 3 * (size_t)P.n_envs; }
+__device__ __forceinline__ void plan_count(const EnvParams& P, const float* actions)
+{
+    __shared__ int acc[3];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    if (tid < 3) acc[tid] = 0;
+    __syncthreads();
+    const int env = (int)blockIdx.x * PLAN_THREADS + tid;
+    const int cls = env < P.n_envs ? plan_class(P, actions, env) : -1;
+    const unsigned long long m0 = wv::ballot(cls == 0), m1 = wv::ballot(cls == 1), m2 = wv::ballot(cls == 2);
+    if (lane == 0) { atomicAdd(&acc[0], __popcll(m0)); atomicAdd(&acc[1], __popcll(m1)); atomicAdd(&acc[2], __popcll(m2)); }
+    __syncthreads();
+    if (tid < 3) plan_wg_counts(P)[3 * (int)blockIdx.x + tid] = acc[tid];
+}
+__device__ __forceinline__ void plan_scatter(const EnvParams& P, const float* actions)
+{
+    __shared__ int tot[3], base[3], wcnt[3][PLAN_THREADS / 64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = PLAN_THREADS / 64;
+    const int wg = (int)blockIdx.x, nwg = (P.n_envs + PLAN_THREADS - 1) / PLAN_THREADS;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (tid < 3) { tot[tid] = 0; base[tid] = 0; }
+    __syncthreads();
+    {
+        const int* cnt = plan_wg_counts(P);
+        int t0 = 0, t1 = 0, t2 = 0, b0 = 0, b1 = 0, b2 = 0;
+        for (int w = tid; w < nwg; w += PLAN_THREADS) {
+            const int c0 = cnt[3 * w], c1 = cnt[3 * w + 1], c2 = cnt[3 * w + 2];
+            t0 += c0; t1 += c1; t2 += c2;
+            if (w < wg) { b0 += c0; b1 += c1; b2 += c2; }
+        }
+        if (t0 | t1 | t2) { atomicAdd(&tot[0], t0); atomicAdd(&tot[1], t1); atomicAdd(&tot[2], t2); }
+        if (b0 | b1 | b2) { atomicAdd(&base[0], b0); atomicAdd(&base[1], b1); atomicAdd(&base[2], b2); }
+    }
+    const int env = wg * PLAN_THREADS + tid;
+    const int cls = env < P.n_envs ? plan_class(P, actions, env) : -1;
+    const unsigned long long m0 = wv::ballot(cls == 0), m1 = wv::ballot(cls == 1), m2 = wv::ballot(cls == 2);
+    if (lane == 0) { wcnt[0][wave] = __popcll(m0); wcnt[1][wave] = __popcll(m1); wcnt[2][wave] = __popcll(m2); }
+    __syncthreads();
+    const int n0all = tot[0], n1 = tot[1], n2all = tot[2];
+    const bool promote = PMG_FD_DIV > 0 && P.nb == 1 && !P.joint_control && (long long)n1 * PMG_FD_DIV <= P.n_envs &&
+                         n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget;
+    int b0 = base[0], b1 = base[1], b2 = base[2];
+    for (int w = 0; w < wave && w < waves; w++) { b0 += wcnt[0][w]; b1 += wcnt[1][w]; b2 += wcnt[2][w]; }
+    if (cls == 0) P.sched[2 + b0 + __popcll(m0 & below)] = env;
+    else if (cls == 1 && promote) P.sched[2 + n0all + b1 + __popcll(m1 & below)] = env;
+    else if (cls == 1) P.sched[2 + P.n_envs + b1 + __popcll(m1 & below)] = env;
+    else if (cls == 2) P.sched[2 + P.n_envs + (promote ? 0 : n1) + b2 + __popcll(m2 & below)] = env;
+    if (wg == 0 && tid == 0) {
+        P.sched[0] = promote ? n0all + n1 : n0all;
+        P.sched[1] = promote ? n2all : n1 + n2all;
         P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
     }
 }

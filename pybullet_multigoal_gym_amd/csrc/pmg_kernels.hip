@@ -43,6 +43,15 @@ __global__ void __launch_bounds__(1024) pmg_k_plan(pmg::EnvParams P, const float
     pmg::plan_all(P, actions);
 }
 
+__global__ void __launch_bounds__(1024) pmg_k_plan_count(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    pmg::plan_count(P, actions);
+}
+__global__ void __launch_bounds__(1024) pmg_k_plan_scatter(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    pmg::plan_scatter(P, actions);
+}
+
 __global__ void __launch_bounds__(64) pmg_k_reset(pmg::EnvParams P, const unsigned char* __restrict__ mask)
 {
     pmg::reset_env(P, mask);
@@ -136,9 +145,14 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    /* the single-workgroup plan covers PLAN_MAX_TILES * 64 envs; beyond that the identity schedule stays and
-     * pmg_api.cpp has switched the fast paths off */
+    /* one workgroup plans up to PLAN_MAX_TILES * 64 = 65 536 envs in one launch (13 us); larger batches take the two-pass
+     * plan over ceil(N / 1024) workgroups: same lists, every batch size keeps the fast paths */
     if (P.n_envs <= pmg::PLAN_MAX_TILES * 64) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    else {
+        const int nwg = (P.n_envs + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS;
+        hipLaunchKernelGGL(pmg_k_plan_count, dim3(nwg), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+        hipLaunchKernelGGL(pmg_k_plan_scatter, dim3(nwg), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    }
     return hipGetLastError();
 }
 /* one free object: the fast-path list four envs per wavefront (pmg_packed.h; 31 KB of LDS per workgroup).  The envs

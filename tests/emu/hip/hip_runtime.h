@@ -18,6 +18,8 @@ struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned 
 static inline const char* hipGetErrorString(hipError_t) { return "emulated hip error"; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; } /* ranks of a multi-process test each pick "their" device */
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; } /* an MI355X */
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipHostMalloc(void** p, size_t n) { return hipMalloc(p, n); }

@@ -391,3 +391,37 @@ def test_device_narrowphase_matches_oracle_on_random_pairs(emu_library, kind):
             assert np.abs(got[order_g][:, 9] - ref[order_r][:, 9]).max() < 2e-5
             assert np.abs(got[order_g][:, 0:6] - ref[order_r][:, 0:6]).max() < 5e-5
     assert checked > 80
+
+
+@pytest.mark.parametrize('nb,frac_down', [(0, 0.3), (1, 0.05), (1, 0.4)])
+def test_two_pass_plan_writes_the_same_lists_as_the_single_workgroup_plan(built, nb, frac_down):
+    """Batches beyond 65 536 envs are planned by ceil(N / 1024) workgroups in two passes (pmg_k_plan_count /
+    pmg_k_plan_scatter).  On a batch both plans can take (3 000 envs = three workgroups, the last one ragged) they must
+    write identical launch lists and counts -- for reach, and for one free object with few / many envs down at the
+    table (the promotion rule decided from the grand totals, on either side of its threshold)."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so'))
+    N, adim = 3000, 3
+    rs = np.random.RandomState(nb * 7 + int(frac_down * 100))
+    hot = np.zeros((N, 32), np.float32)
+    hot[:, 18] = rs.uniform(-0.67, -0.37, N); hot[:, 19] = rs.uniform(-0.2, 0.2, N)
+    hot[:, 20] = np.where(rs.uniform(0, 1, N) < frac_down, 0.175 + rs.uniform(0, 0.01, N), rs.uniform(0.19, 0.5, N))
+    blocks = np.zeros((N, 13 * max(nb, 1)), np.float32)
+    blocks[:, 0] = rs.uniform(-0.64, -0.40, N); blocks[:, 1] = rs.uniform(-0.15, 0.15, N); blocks[:, 2] = 0.175; blocks[:, 6] = 1
+    near = rs.uniform(0, 1, N) < 0.1                       # some grippers right at their object: class 0
+    hot[near, 18:21] = blocks[near, 0:3] + np.float32([0.0, 0.0, 0.02])
+    actions = rs.uniform(-1, 1, (N, adim)).astype(np.float32)
+    out = []
+    for two_pass in (0, 1):
+        sc = np.full(3 + 3 * N, -7, np.int32)
+        rc = lib.pmge_probe_plan(C.c_int(N), C.c_int(nb), hot.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
+                                 actions.ctypes.data_as(C.c_void_p), C.c_int(adim), C.c_int(1536), C.c_int(two_pass),
+                                 sc.ctypes.data_as(C.c_void_p))
+        assert rc == 0
+        out.append(sc)
+    a, b = out
+    n0, n1 = int(a[0]), int(a[1])
+    assert n0 + n1 == N and (n0, n1) == (int(b[0]), int(b[1])) and 0 < n0 < N
+    assert np.array_equal(a[2:2 + n0], b[2:2 + n0]) and np.array_equal(a[2 + N:2 + N + n1], b[2 + N:2 + N + n1])
+    assert a[2 + 2 * N] == 0 and b[2 + 2 * N] == 0
+    assert sorted(np.concatenate([b[2:2 + n0], b[2 + N:2 + N + n1]]).tolist()) == list(range(N))    # a partition of the batch

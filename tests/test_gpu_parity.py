@@ -561,19 +561,42 @@ def test_full_size_multi_block_properties(built, task):
     env.close()
 
 
-def test_batches_beyond_the_plan_kernel_fall_back_to_identity_order(built):
-    """65 536 envs is what the single-workgroup plan kernel partitions; a larger batch must still step EVERY env
-    (one env per wavefront, identity order)."""
-    N = 65536 + 256
+def _expected_schedule(env, actions):
+    """What pmg_k_plan must write for a reach batch under tip control (contact_prone() of pmg_kernels.h restated):
+    the envs whose tip target is, or will be after this action, within 12 mm of the lower clip plane -- in env order --
+    then everybody else in env order."""
+    st = env.get_state()
+    z = st[:, 20].astype(np.float32)
+    zn = np.clip(z + actions[:, 2] * np.float32(0.01), np.float32(0.175), np.float32(0.55))
+    prone = np.minimum(z, zn) < np.float32(0.175) + np.float32(0.012)
+    idx = np.arange(len(st))
+    return idx[prone], idx[~prone]
+
+
+@pytest.mark.parametrize('N', [4096, 65536 + 256, 131072])
+def test_plan_schedule_at_every_batch_size(built, N):
+    """One plan workgroup partitions up to 65 536 envs; larger batches take the two-pass plan over ceil(N / 1024)
+    workgroups (pmg_k_plan_count / pmg_k_plan_scatter).  Either way the launch lists read back from the device are the
+    stable partition of the batch -- contact-prone envs first, in env order, then the rest in env order -- every env is
+    on exactly one list, steps once, and the fast path (four envs per wavefront) stays on at every size."""
     env = pmg.make_env(task='reach', num_envs=N, seed=0, seed_stride=1)
     env.reset()
+    rs = np.random.RandomState(3)
+    for t in range(12):       # walk a good part of the batch down to the table
+        a = rs.uniform(-1, 1, (N, 3)).astype(np.float32)
+        a[:, 2] = -np.abs(a[:, 2])
+        env.step(a)
     s0 = env.get_state()
-    a = np.zeros((N, 3), np.float32)
-    a[:, 0] = 1.0
+    a = rs.uniform(-1, 1, (N, 3)).astype(np.float32)
+    want_prone, want_free = _expected_schedule(env, a)
     env.step(a)
+    sch = env.handle.schedule()
+    assert 0.02 * N < len(want_prone) < 0.9 * N
+    assert np.array_equal(sch['prone'], want_prone) and np.array_equal(sch['free'], want_free)
     s1 = env.get_state()
-    assert (s1[:, 29] == 1).all()                                   # every env advanced its step counter
-    assert np.allclose(s1[:, 18] - s0[:, 18], 0.01, atol=1e-6)      # ... and its tip target
+    assert (s1[:, 29] == s0[:, 29] + 1).all()                                   # every env advanced its step counter once
+    want = np.clip(s0[:, 18:21] + a * np.float32(0.01), [-0.67, -0.2, 0.175], [-0.37, 0.2, 0.55])
+    assert np.abs(s1[:, 18:21] - want).max() < 1e-6                             # ... by its own action
     env.close()
 
 
