@@ -154,6 +154,15 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
             float d2 = (t[0] - p[0]) * (t[0] - p[0]) + (t[1] - p[1]) * (t[1] - p[1]) + (t[2] - p[2]) * (t[2] - p[2]);
             near = near || d2 < 0.065f * 0.065f;
         }
+        if (P.chest >= 0) {
+            /* the chest: its walls / door / lid / handle add contacts once the gripper can TOUCH them -- the gripper-base
+             * cylinder (radius 0.05 about the tool axis) reaches the front face at x = -0.592 (door) / -0.555 (the lid's
+             * handle) first; sideways the finger boxes reach 4.5 cm from the tip (front door: slides to y = +0.19; lid:
+             * slides to x = -0.805); 1.2 cm for this step's target motion.  A prediction only: an env of the fast-path
+             * list whose contacts do not fit its store is recomputed by the redo pass */
+            const float x0 = P.chest == 0 ? -0.705f : -0.805f, x1 = P.chest == 0 ? -0.592f : -0.555f, y1 = P.chest == 0 ? 0.19f : 0.07f;
+            near = near || (t[0] > x0 - 0.064f && t[0] < x1 + 0.064f && t[1] > -0.07f - 0.064f && t[1] < y1 + 0.064f && t[2] < 0.272f + 0.015f);
+        }
         return near;
     }
     float z = hot[20];                                    /* tip target: the tip is within mm of it */
@@ -163,6 +172,7 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
 /* one 1024-thread workgroup partitions all envs (stable, no atomics): per-wave ballots, counts of
  * every (chunk, wave) tile in LDS, then each tile scatters at its exclusive prefix */
 constexpr int PLAN_THREADS = 1024, PLAN_MAX_TILES = 1024;
+constexpr int PLAN_SINGLE_MAX = 16384;   /* the single-workgroup plan serves batches up to here (<= PLAN_MAX_TILES * 64) */
 #ifndef PMG_FD_DIV
 #define PMG_FD_DIV 8
 #endif

@@ -145,9 +145,10 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    /* one workgroup plans up to PLAN_MAX_TILES * 64 = 65 536 envs in one launch (13 us); larger batches take the two-pass
-     * plan over ceil(N / 1024) workgroups: same lists, every batch size keeps the fast paths */
-    if (P.n_envs <= pmg::PLAN_MAX_TILES * 64) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    /* one workgroup plans a batch in one launch (13 us at 4096 envs, but its 1024 threads walk the batch in chunks: 0.9 ms
+     * at 65 536); beyond PLAN_SINGLE_MAX envs the two-pass plan over ceil(N / 1024) workgroups takes over: same lists
+     * (tests/test_emulated_kernels.py), every batch size keeps the fast paths */
+    if (P.n_envs <= pmg::PLAN_SINGLE_MAX) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     else {
         const int nwg = (P.n_envs + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS;
         hipLaunchKernelGGL(pmg_k_plan_count, dim3(nwg), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
@@ -197,9 +198,32 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_multi(pmg::En
     if ((int)blockIdx.x >= redo[0]) return;
     pmg::step_env<5, 48, false>(P, actions, redo[1 + blockIdx.x]);
 }
+/* chest tasks: the same two-list split -- list 0 (gripper at the chest or at a block) keeps the full layout (48 contacts,
+ * a stage slot per pair, 32 000 B = 5 workgroups per CU), list 1 runs ContactLds<6, 30> with ranked stage slots
+ * (CHEST_SMALL); an env of list 1 whose contacts or surviving pairs overflow is recomputed by pmg_k_redo_chest */
+template <int CYL>
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_chest(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    const int* redo = P.sched + 2 + 2 * P.n_envs;
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<6, 48, CYL>(P, actions, redo[1 + blockIdx.x]);
+}
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
                            hipEvent_t ev_fork, hipEvent_t ev_join)
 {
+    if (P.chest >= 0 && packed) {
+        (void)hipEventRecord(ev_fork, s);
+        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+        (void)hipEventRecord(ev_join, side);
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        (void)hipStreamWaitEvent(s, ev_join, 0);
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_redo_chest<2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_redo_chest<3>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        return hipGetLastError();
+    }
     if (P.chest >= 0) {
         /* chest tasks: one env per wavefront with the chest layout (door slot + chest pairs, 47 KB of LDS) */
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step<6, 48, 2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);

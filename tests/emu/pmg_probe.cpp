@@ -82,7 +82,7 @@ extern "C" int pmge_probe_plan(int n_envs, int nb, const float* hot, const float
     std::vector<int> sc(3 + 3 * (size_t)n_envs + 3 * (size_t)nwg, -1);
     P.sched = sc.data();
     if (!two_pass) {
-        if (n_envs > PLAN_MAX_TILES * 64) return -1;
+        if (n_envs > PLAN_MAX_TILES * 64) return -1;   /* (the launcher switches to two passes at PLAN_SINGLE_MAX already) */
         emu::launch(1, PLAN_THREADS, [&]() { plan_all(P, actions); });
     } else {
         emu::launch(nwg, PLAN_THREADS, [&]() { plan_count(P, actions); });

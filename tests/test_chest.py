@@ -302,3 +302,44 @@ def test_emulated_finger_opens_the_door_by_its_handle(emu_library):
         _compare(o, oo, 5e-2, 1e-4)   # poses tight; the velocities of a finger scraping along the handle are noisy
     assert oo['achieved_goal'][0, 0] > 0.015                      # pushed open by almost 2 cm in three steps
     env.close()
+
+
+def test_emulated_chest_two_list_split_and_redo(emu_library):
+    """The chest tasks' launch plan (round 3): an env whose gripper can touch the chest or a block keeps the full layout
+    (list 0: 48 contacts, a stage slot per pair), everybody else runs ContactLds<6, 30> with stage slots handed out by
+    rank among the surviving pairs (list 1, 20 KB of LDS instead of 32), and a list-1 env whose contacts do not fit is
+    recomputed by pmg_k_redo_chest.  Three envs, one of each kind, against the oracle."""
+    nb = 5
+    env = _quiet_env('chest_push', emu_library, num_block=nb, seed=5)
+    env.close()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        env = pmg.make_env(task='chest_push', num_envs=3, seed=5, seed_stride=1, num_block=nb, _library=emu_library)
+    ora = O.OracleEnv('chest_push', 3, num_block=nb, seed_base=5, seed_stride=1)
+    ora.reset()
+    env.reset(), ora.reset()
+    # env 1: the oracle flies the gripper to the chest's front door (as the door-dragging test above)
+    a = np.zeros((3, 3), np.float32)
+    for t in range(7):
+        a[:] = 0
+        a[1] = [-1, 0, 1]
+        ora.step(a)
+    st = ora.get_state()
+    # env 2: gripper far from everything, the five blocks in a tight row: 20 table contacts + 4 x 4 block x block = 36 > 30
+    for b in range(nb):
+        st[2, 64 + 13 * b:77 + 13 * b] = [-0.45, -0.09 + 0.0302 * b, 0.175, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+    # env 0: gripper where it starts, the blocks spread out away from it
+    for b, y in enumerate([-0.15, -0.09, 0.09, 0.15, 0.21]):
+        st[0, 64 + 13 * b:77 + 13 * b] = [-0.45, y, 0.175, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0]
+    ora.set_state(st)
+    env.set_state(ora.get_state())
+    a[:] = 0
+    a[1] = [-1, 0, 0]
+    for t in range(2):
+        o, r, d, info = env.step(a)
+        oo, ro, do, oko = ora.step(a)
+        sch = env.handle.schedule()
+        assert list(sch['prone']) == [1] and sorted(sch['free']) == [0, 2] and list(sch['redo']) == [2], sch
+        _compare(o, oo, 2e-3)
+        assert np.array_equal(r, ro)
+    env.close()

@@ -573,10 +573,11 @@ def _expected_schedule(env, actions):
     return idx[prone], idx[~prone]
 
 
-@pytest.mark.parametrize('N', [4096, 65536 + 256, 131072])
+@pytest.mark.parametrize('N', [4096, 16384 + 64, 65536 + 256, 131072])
 def test_plan_schedule_at_every_batch_size(built, N):
-    """One plan workgroup partitions up to 65 536 envs; larger batches take the two-pass plan over ceil(N / 1024)
-    workgroups (pmg_k_plan_count / pmg_k_plan_scatter).  Either way the launch lists read back from the device are the
+    """One plan workgroup partitions batches up to 16 384 envs; larger ones take the two-pass plan over ceil(N / 1024)
+    workgroups (pmg_k_plan_count / pmg_k_plan_scatter; round 2 stopped planning at 65 536 envs and fell back to one env
+    per wavefront in identity order).  Either way the launch lists read back from the device are the
     stable partition of the batch -- contact-prone envs first, in env order, then the rest in env order -- every env is
     on exactly one list, steps once, and the fast path (four envs per wavefront) stays on at every size."""
     env = pmg.make_env(task='reach', num_envs=N, seed=0, seed_stride=1)
