@@ -349,6 +349,12 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         int cus = 256;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus <= 0) cus = 256;
         e->P.wave_budget = 6 * cus;
+        /* measured on chest_push-4 / chest_pick_and_place-4 x 4096 (tools/chest_exp.sh): 6.5 cm / 6.4 cm put 40-65 % of a
+         * random-policy batch on the full-layout list (0.337 M); 5 cm / 2 cm: 20 %, no redo, 0.388 / 0.416 M */
+        e->P.near_r = e->P.chest >= 0 ? 0.05f : 0.065f;
+        e->P.chest_reach = 0.02f;
+        if (const char* nr = getenv("PMG_NEAR_R")) e->P.near_r = (float)atof(nr);   /* (tuning experiments) */
+        if (const char* cr = getenv("PMG_CHEST_REACH")) e->P.chest_reach = (float)atof(cr);
     }
     CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->d_mask, N));

@@ -24,6 +24,8 @@ struct EnvParams {
                                           the door's joint position, velocity and motor latch live in goal[0..2] */
     double goals_per_curriculum;
     int adim, odim, pdim, gdim, packed;
+    float chest_reach;      /* plan: how far in front of the chest's front face a tip target counts as "at the chest" */
+    float near_r;           /* plan: a tip target within this distance of a free object sends the env to the full-store list */
     int wave_budget;        /* 1.5 wavefronts per SIMD of THIS device (6 x CUs: 1536 on an MI355X): pmg_k_plan's promotion rule */
     float thr;
     float ee_lo[3], ee_hi[3];
@@ -152,16 +154,17 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
         for (int b = 0; b < P.nb; b++) {
             const float* p = P.blocks + ((size_t)env * P.nb + b) * BLOCK_DIM;
             float d2 = (t[0] - p[0]) * (t[0] - p[0]) + (t[1] - p[1]) * (t[1] - p[1]) + (t[2] - p[2]) * (t[2] - p[2]);
-            near = near || d2 < 0.065f * 0.065f;
+            near = near || d2 < P.near_r * P.near_r;
         }
         if (P.chest >= 0) {
-            /* the chest: its walls / door / lid / handle add contacts once the gripper can TOUCH them -- the gripper-base
-             * cylinder (radius 0.05 about the tool axis) reaches the front face at x = -0.592 (door) / -0.555 (the lid's
-             * handle) first; sideways the finger boxes reach 4.5 cm from the tip (front door: slides to y = +0.19; lid:
-             * slides to x = -0.805); 1.2 cm for this step's target motion.  A prediction only: an env of the fast-path
-             * list whose contacts do not fit its store is recomputed by the redo pass */
+            /* the chest: its walls / door / lid / handle add contacts once the fingers can TOUCH them: the finger boxes
+             * (1.25 cm from the tool axis in x, 4.5 cm in y) against the front face at x = -0.592 (door) / -0.555 (the
+             * lid's handle), `chest_reach` = that + this step's target motion; the door slides to y = +0.19, the lid to
+             * x = -0.805.  (The gripper-base cylinder grazes the door's top edge earlier, with <= 4 more contacts: they
+             * fit.)  A prediction only: an env of the fast-path list whose contacts do not fit its store is recomputed by
+             * the redo pass */
             const float x0 = P.chest == 0 ? -0.705f : -0.805f, x1 = P.chest == 0 ? -0.592f : -0.555f, y1 = P.chest == 0 ? 0.19f : 0.07f;
-            near = near || (t[0] > x0 - 0.064f && t[0] < x1 + 0.064f && t[1] > -0.07f - 0.064f && t[1] < y1 + 0.064f && t[2] < 0.272f + 0.015f);
+            near = near || (t[0] > x0 - 0.064f && t[0] < x1 + P.chest_reach && t[1] > -0.07f - 0.064f && t[1] < y1 + 0.064f && t[2] < 0.272f + 0.015f);
         }
         return near;
     }

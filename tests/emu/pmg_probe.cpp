@@ -73,7 +73,7 @@ extern "C" int pmge_probe_plan(int n_envs, int nb, const float* hot, const float
     using namespace pmg;
     EnvParams P;
     memset(&P, 0, sizeof(P));
-    P.n_envs = n_envs; P.nb = nb; P.adim = adim; P.chest = -1; P.wave_budget = wave_budget; P.has_obj = nb > 0;
+    P.n_envs = n_envs; P.nb = nb; P.adim = adim; P.chest = -1; P.wave_budget = wave_budget; P.has_obj = nb > 0; P.near_r = 0.065f;
     const float lo[3] = {-0.67f, -0.2f, 0.175f}, hi[3] = {-0.37f, 0.2f, 0.55f};
     for (int a = 0; a < 3; a++) { P.ee_lo[a] = lo[a]; P.ee_hi[a] = hi[a]; }
     P.hot = const_cast<float*>(hot);

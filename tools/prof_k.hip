@@ -17,7 +17,7 @@ int main(int argc, char** argv)
     P.adim = task == 4 ? 4 : 3; P.odim = task == 0 ? 3 : (task == 4 ? 72 : 20); P.pdim = task == 0 ? 3 : (task == 4 ? 16 : 7); P.gdim = task == 4 ? 12 : 3; P.packed = P.odim + P.pdim + 9; P.thr = 0.05f;
     float lo[3] = {-0.67f, -0.2f, 0.175f}, hi[3] = {-0.37f, 0.2f, 0.55f}, tc[3] = {-0.52f, 0, 0.08f}, th[3] = {0.25f, 0.35f, 0.08f};
     for (int a = 0; a < 3; a++) { P.ee_lo[a] = lo[a]; P.ee_hi[a] = hi[a]; P.table_c[a] = tc[a]; P.table_h[a] = th[a]; }
-    P.table_mu = 0.1f;
+    P.table_mu = 0.1f; P.near_r = 0.065f; P.wave_budget = 1536;
     std::vector<float> hot(N * 32, 0.f), goal(N * 16, 0.f), blk(N * 13 * 4, 0.f), act(N * 4, 0.f);
     // joint pose with the tip at z ~ 0.176 (push start pose): from the oracle's reset
     float q0[9] = {0.f, -0.4712f, 0.f, 1.9904f, 0.f, -0.6800f, 0.f, 0.035f, 0.035f};

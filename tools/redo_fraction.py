@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pybullet_multigoal_gym_amd as pmg
 task = sys.argv[1] if len(sys.argv) > 1 else 'push'
 N = 4096
-env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1)
+env = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, num_block=4)
 rs = np.random.RandomState(12345)
 env.reset()
 fr = []
