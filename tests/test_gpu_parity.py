@@ -697,3 +697,36 @@ def test_compute_reward_batch_multi_block_goals(built, kw, G):
     r, ok = dense._compute_reward(ag, dg)
     assert np.abs(r + np.linalg.norm(ag.astype(np.float64) - dg, axis=-1)).max() < 1e-5
     dense.close()
+
+
+@pytest.mark.parametrize('task,kw', [('reach', {}), ('push', {}), ('block_stack', {'num_block': 4, 'use_curriculum': True, 'num_goals_to_generate': 200}),
+                                     ('chest_push', {'num_block': 2})])
+def test_checkpoint_round_trip_on_device(built, hip_library, task, kw):
+    """get_checkpoint() / set_checkpoint() (state rows + the per-env MT19937 streams + the curriculum switch) on the
+    device: restored into the same env and into a fresh one, 64 envs continue bit-identically through steps, masked
+    resets (new goals from the restored streams) and curriculum bookkeeping; a malformed RNG state is refused."""
+    from test_host_api import _checkpoint_round_trip
+    _checkpoint_round_trip(hip_library, task, 64, 3, 6, **kw)
+
+
+def test_sharded_push_agrees_with_the_unsharded_batch_to_float32_tolerance(built):
+    """One-object tasks: pmg_k_plan moves the fingers-down class between the packed kernel (LDS rows, 16-lane layout) and
+    the one-env kernel (row space) depending on BATCH-WIDE counts, and the two sum in different float32 orders -- so the
+    same env with the same seed and actions is reproducible bit for bit only within the same batch composition (DESIGN.md
+    section 8).  Across shard sizes it agrees to float32 tolerance: 512 envs in one batch against two shards of 256."""
+    N, T = 512, 12
+    full = pmg.make_env(task='push', num_envs=N, seed=9, seed_stride=1)
+    lo = pmg.make_env(task='push', num_envs=N // 2, seed=9, seed_stride=1)
+    hi = pmg.make_env(task='push', num_envs=N // 2, seed=9, seed_stride=1, env_index_offset=N // 2)
+    of, ol, oh = full.reset(), lo.reset(), hi.reset()
+    assert np.array_equal(of['desired_goal'], np.concatenate([ol['desired_goal'], oh['desired_goal']]))   # seeds follow the global index
+    rs = np.random.RandomState(2)
+    for t in range(T):
+        a = rs.uniform(-1, 1, (N, 3)).astype(np.float32)
+        a[:, 2] = -np.abs(a[:, 2])                      # fingers down: the class the plan moves around
+        of = full.step(a)[0]
+        ol, oh = lo.step(a[:N // 2])[0], hi.step(a[N // 2:])[0]
+    err = np.abs(of['observation'][:, :6] - np.concatenate([ol['observation'], oh['observation']])[:, :6]).max(1)
+    print('sharded vs unsharded push, tip + block position after %d steps: max %.2e median %.2e, beyond 1e-4: %d of %d' % (T, err.max(), np.median(err), (err > 1e-4).sum(), N))
+    assert np.median(err) < 1e-5 and (err > 1e-3).mean() <= 0.01
+    full.close(), lo.close(), hi.close()

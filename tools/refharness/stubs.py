@@ -245,7 +245,7 @@ def install():
     """Put the stand-ins into sys.modules and the reference on sys.path.  Refuses to shadow a real gym / pybullet."""
     for real in ('gym', 'pybullet'):
         if real in sys.modules and not getattr(sys.modules[real], '__pmg_stub__', False):
-            raise RuntimeError('%s is really installed here: capture fixtures with tools/capture_reference.py instead' % real)
+            raise RuntimeError('%s is really installed here: capture fixtures with `tools/gen_reference_fixtures.py --real` instead' % real)
     from . import fake_bullet
     seeding = _module('gym.utils.seeding', np_random=np_random, hash_seed=hash_seed, create_seed=create_seed)
     utils = _module('gym.utils', seeding=seeding)
