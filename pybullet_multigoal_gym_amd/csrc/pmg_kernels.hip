@@ -58,29 +58,44 @@ __global__ void __launch_bounds__(64) pmg_k_reset(pmg::EnvParams P, const unsign
 }
 
 /* _compute_reward on [B, G] batches (HER relabelling): kuka_single_step_base_env.py:237-244.
- * HBM-bound: 2*G*4 bytes in, 5 bytes out per item.  G == 3 (every single-object task): one thread
- * owns 4 consecutive items = 3 x 16-byte loads per array (fully coalesced dwordx4), one dwordx4
- * store of rewards and one dword of flags; grid-stride over a bounded grid (Guideline 11/13). */
+ * HBM-bound: 2*G*4 bytes in, 5 bytes out per item, each touched once -- so every access is non-temporal (streams past
+ * the caches).  G == 3 (every single-object task): a workgroup owns 256 quads of 4 items = 3 x 256 float4 per array,
+ * read as three fully coalesced float4 sweeps (lane = consecutive 16 bytes) into LDS; thread t then takes the three
+ * float4 of ITS quad from LDS (stride 3: conflict-free), computes four rewards and stores one float4 of rewards and one
+ * dword of flags, contiguously.  Measured (tools/reward_variants.hip, 64 Mi pairs): 6.1-6.3 TB/s = the float4-copy
+ * ceiling of the part (MI355X_MICROARCH.md: 6.29), against 5.0-5.6 for the thread-owns-three-strided-float4 version
+ * of rounds 1-2 (with or without non-temporal stores, one or two quads in flight). */
 __global__ void __launch_bounds__(256) pmg_k_reward3(const float4* __restrict__ ag, const float4* __restrict__ dg, long long quads,
                                                     float thr, int binary, float4* __restrict__ reward,
                                                     unsigned int* __restrict__ ok)
 {
-    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (long long)gridDim.x * blockDim.x) {
-        float4 a0 = ag[3 * q], a1 = ag[3 * q + 1], a2 = ag[3 * q + 2];
-        float4 d0 = dg[3 * q], d1 = dg[3 * q + 1], d2 = dg[3 * q + 2];
-        float e[12] = {a0.x - d0.x, a0.y - d0.y, a0.z - d0.z, a0.w - d0.w, a1.x - d1.x, a1.y - d1.y,
-                       a1.z - d1.z, a1.w - d1.w, a2.x - d2.x, a2.y - d2.y, a2.z - d2.z, a2.w - d2.w};
-        float r[4];
-        unsigned int flags = 0;
+    __shared__ float4 sa[3 * 256], sd[3 * 256];
+    const int t = (int)threadIdx.x;
+    for (long long base = (long long)blockIdx.x * 256; base < quads; base += (long long)gridDim.x * 256) {
+        const long long n = quads - base < 256 ? quads - base : 256;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            float d = sqrtf(e[3 * i] * e[3 * i] + e[3 * i + 1] * e[3 * i + 1] + e[3 * i + 2] * e[3 * i + 2]);
-            bool na = d > thr;
-            r[i] = binary ? (na ? -1.f : -0.f) : -d;
-            flags |= (na ? 0u : 1u) << (8 * i);
+        for (int k = 0; k < 3; k++) {
+            const long long w = k * 256 + t;
+            if (w < 3 * n) { sa[w] = nt::load4(&ag[3 * base + w]); sd[w] = nt::load4(&dg[3 * base + w]); }
         }
-        if (reward) reward[q] = make_float4(r[0], r[1], r[2], r[3]);
-        if (ok) ok[q] = flags;
+        __syncthreads();
+        if (t < n) {
+            const float4 a0 = sa[3 * t], a1 = sa[3 * t + 1], a2 = sa[3 * t + 2], d0 = sd[3 * t], d1 = sd[3 * t + 1], d2 = sd[3 * t + 2];
+            float e[12] = {a0.x - d0.x, a0.y - d0.y, a0.z - d0.z, a0.w - d0.w, a1.x - d1.x, a1.y - d1.y,
+                           a1.z - d1.z, a1.w - d1.w, a2.x - d2.x, a2.y - d2.y, a2.z - d2.z, a2.w - d2.w};
+            float r[4];
+            unsigned int flags = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float d = sqrtf(e[3 * i] * e[3 * i] + e[3 * i + 1] * e[3 * i + 1] + e[3 * i + 2] * e[3 * i + 2]);
+                bool na = d > thr;
+                r[i] = binary ? (na ? -1.f : -0.f) : -d;
+                flags |= (na ? 0u : 1u) << (8 * i);
+            }
+            if (reward) nt::store4(make_float4(r[0], r[1], r[2], r[3]), &reward[base + t]);
+            if (ok) nt::store(flags, &ok[base + t]);
+        }
+        __syncthreads();
     }
 }
 /* multi-block goals (G = 3 * num_block, up to 19 with the gripper tail): a workgroup owns 256 consecutive items = one
@@ -104,11 +119,11 @@ __global__ void __launch_bounds__(256) pmg_k_reward_flat(const float* __restrict
         for (long long w = t; w < words; w += 256) {
             float s;
             if (VEC == 4) {
-                float4 x = ((const float4*)a)[w], y = ((const float4*)d)[w];
+                float4 x = nt::load4(&((const float4*)a)[w]), y = nt::load4(&((const float4*)d)[w]);
                 float e0 = x.x - y.x, e1 = x.y - y.y, e2 = x.z - y.z, e3 = x.w - y.w;
                 s = (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
             } else {
-                float e = a[w] - d[w];
+                float e = nt::load(&a[w]) - nt::load(&d[w]);
                 s = e * e;
             }
             part[w] = s;
@@ -307,7 +322,7 @@ hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int 
     if (G == 3 && aligned && B >= 4) {
         long long quads = B / 4;
         long long want = (quads + 255) / 256;
-        unsigned grid = (unsigned)(want < 4096 ? want : 4096); /* 256 CUs x 16 blocks, grid-stride the rest */
+        unsigned grid = (unsigned)(want < 65536 ? want : 65536); /* a workgroup per 256 quads (measured best), grid-stride beyond 64 Mi items */
         hipLaunchKernelGGL(pmg_k_reward3, dim3(grid), dim3(256), 0, s, (const float4*)ag, (const float4*)dg, quads, thr, binary,
                            (float4*)reward, (unsigned int*)ok);
         first = quads * 4;

@@ -15,6 +15,15 @@
 
 #include <hip/hip_runtime.h>
 
+/* non-temporal (streaming) global accesses of the HBM-bound reward kernels: data touched exactly once */
+namespace nt {
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load4(const float4* p) { v4f v = __builtin_nontemporal_load((const v4f*)p); return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void store4(float4 r, float4* p) { v4f v = {r.x, r.y, r.z, r.w}; __builtin_nontemporal_store(v, (v4f*)p); }
+__device__ __forceinline__ float load(const float* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void store(unsigned int v, unsigned int* p) { __builtin_nontemporal_store(v, p); }
+}  // namespace nt
+
 namespace wv {
 
 constexpr int LANES = 64; /* lanes that cooperate on one env */

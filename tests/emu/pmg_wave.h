@@ -12,6 +12,13 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 
+namespace nt {   /* the product's non-temporal accesses: plain ones here */
+static inline float4 load4(const float4* p) { return *p; }
+static inline void store4(float4 r, float4* p) { *p = r; }
+static inline float load(const float* p) { return *p; }
+static inline void store(unsigned int v, unsigned int* p) { *p = v; }
+}  // namespace nt
+
 namespace wv {
 constexpr int LANES = 64;
 inline int lane() { return (int)threadIdx.x & 63; }
