@@ -119,11 +119,11 @@ __global__ void __launch_bounds__(256) pmg_k_reward_flat(const float* __restrict
         for (long long w = t; w < words; w += 256) {
             float s;
             if (VEC == 4) {
-                float4 x = nt::load4(&((const float4*)a)[w]), y = nt::load4(&((const float4*)d)[w]);
+                float4 x = ((const float4*)a)[w], y = ((const float4*)d)[w];   /* (non-temporal loads measured SLOWER here: 5.31 vs 5.49-5.70 TB/s at G = 12) */
                 float e0 = x.x - y.x, e1 = x.y - y.y, e2 = x.z - y.z, e3 = x.w - y.w;
                 s = (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
             } else {
-                float e = nt::load(&a[w]) - nt::load(&d[w]);
+                float e = a[w] - d[w];
                 s = e * e;
             }
             part[w] = s;
