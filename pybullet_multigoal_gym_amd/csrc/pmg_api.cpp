@@ -118,6 +118,7 @@ struct pmg_env {
     long long ev_launches = 0;
     bool ever_reset = false;
     int packed = 1;                   /* reach: contact-free envs four per wavefront (PMG_PACKED=0 switches it off) */
+    int two_wave = 1;                 /* reach: the two-wavefront kernel for steps with contact-prone envs (PMG_REACH_TWO_WAVES=0: never) */
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
     char err[512] = "";
@@ -345,6 +346,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.sched, (3 + 3 * N + 3 * ((N + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS)) * sizeof(int)));
     if (const char* pk = getenv("PMG_PACKED")) e->packed = atoi(pk) != 0;
+    if (const char* tw = getenv("PMG_REACH_TWO_WAVES")) e->two_wave = atoi(tw) != 0;
     {   /* 1.5 wavefronts per SIMD of this device: how many one-env wavefronts the plan may add to a step */
         int cus = 256;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus <= 0) cus = 256;
@@ -446,8 +448,12 @@ int pmg_step_device(pmg_env* e, const float* d_actions)
     if (e->ev_n == EVENT_POOL) drain_events(e);
     int i = e->ev_n++;
     HIP_TRY(e, pmg_launch_plan(e->P, d_actions, e->stream)); /* launch-order plan (13 us), outside the step-kernel timer */
+    int mode = e->packed;
+    /* reach: steps that have contact-prone envs run the two-wavefront kernel while the contact-free list is at most one
+     * wavefront per SIMD (pmg_kernels.hip); mode 2 launches both kernels and the DEVICE picks one by the plan's count */
+    if (e->packed && e->nb == 0 && !e->cfg.joint_control && e->two_wave && e->dims.num_envs <= (e->P.wave_budget / 6) * 16) mode = 2;
     HIP_TRY(e, hipEventRecord(e->ev_a[i], e->stream));
-    HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream, e->packed, e->side, e->ev_fork, e->ev_join));
+    HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream, mode, e->side, e->ev_fork, e->ev_join));
     HIP_TRY(e, hipEventRecord(e->ev_b[i], e->stream));
     return PMG_OK;
 }

@@ -74,13 +74,13 @@ using pmgx::EnvParams;
 namespace pmg {
 
 /* one env per wavefront: the workgroup's LDS holds this env's contact store and the lane-constant table */
-template <int NB, int MAXC, int CYL>
+template <int NB, int MAXC, int CYL, bool TWO = false>
 __device__ __forceinline__ void step_env(const EnvParams& P, const float* actions, int env)
 {
     __shared__ ContactLds<NB, MAXC> L;
     __shared__ LaneTabStore lcs;
     if (env >= P.n_envs) return;
-    step_env_core<NB, MAXC, CYL>(P, actions, env, L, lcs, true);
+    step_env_core<NB, MAXC, CYL, TWO>(P, actions, env, L, lcs, true);
 }
 
 /* ------------------------------------------------------------------ */

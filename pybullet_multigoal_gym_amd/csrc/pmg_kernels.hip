@@ -24,11 +24,39 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParam
  * lowest ids and start first), the next ceil(n_free / 4) run the contact-free list four envs per wavefront; the
  * grid is sized for the worst case (N) and its surplus workgroups, all at the END of the dispatch order so that they
  * cannot unbalance the placement of the real ones, exit on their first instruction */
-__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_reach(pmg::EnvParams P, const float* __restrict__ actions)
+/* reach, tip control: workgroups [0, n_prone) run the contact-prone list one env per wavefront (the slow waves get the
+ * lowest ids and start first), the next ceil(n_free / 4) run the contact-free list four envs per wavefront; the
+ * grid is sized for the worst case (N) and its surplus workgroups, all at the END of the dispatch order so that they
+ * cannot unbalance the placement of the real ones, exit on their first instruction */
+/* the device-side choice between the two reach kernels: two wavefronts per workgroup as soon as the step has a
+ * contact-prone env (a threshold of 1 / 64 of the batch measured worse: one env on the table already sets the step time) */
+__device__ __forceinline__ bool two_wave_step(int n_prone, int n_envs) { return n_prone > 0; }
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_reach(pmg::EnvParams P, const float* __restrict__ actions, int defer)
 {
     const int b = (int)blockIdx.x, n0 = P.sched[0];
+    if (defer && two_wave_step(n0, P.n_envs)) return;       /* this step belongs to the two-wavefront kernel */
     if (b < n0) pmg::step_env<0, 8, false>(P, actions, P.sched[2 + b]);
     else pmgp::step_group(P, actions, b - n0);
+}
+/* The same with TWO wavefronts per workgroup, for steps that have contact-prone envs (a batched step lasts as long as
+ * its slowest wavefront, and that is one of them): on the contact-prone list wavefront 1 runs the narrowphase of every
+ * substep beside wavefront 0's dynamics (helper_wave_loop: 32 k -> 27 k cycles per substep with both fingers on the
+ * table); on the contact-free list both wavefronts carry four envs each, so that no wavefront of the launch idles.
+ * 4096 envs, staggered episodes: 1.34 -> 1.20 ms per batched step.  A batch WITHOUT contact-prone envs is better off
+ * with one-wavefront workgroups (the dispatcher places 1024 of them exactly one per SIMD: 0.54 ms; 512 two-wave ones:
+ * 0.82 ms), and beyond one packed wavefront per SIMD the second wave slot of every contact-prone env costs more than the
+ * shorter chain saves (16 384 envs: 7.4 vs 8.0 M env-steps/s).  So up to 4096 envs per 256 CUs BOTH kernels are launched
+ * every step and the device picks: each reads the plan's contact-prone count on its first instruction and the one whose
+ * turn it is not exits (an empty launch: ~5 us of a 1.2 ms step; the host cannot know the count without a sync, and a
+ * device-resident rollout queues its steps far ahead of the GPU).  Variants tried:
+ * the idle second wavefront of the contact-free workgroups exiting at once (0.82 ms again); the two lists as two
+ * launches on two streams (1.44 ms). */
+__global__ void __launch_bounds__(128, PMG_WAVES_PER_EU) pmg_k_step_reach2(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    const int b = (int)blockIdx.x, n0 = P.sched[0];
+    if (!two_wave_step(n0, P.n_envs)) return;               /* a (nearly) contact-free step: the one-wavefront kernel's turn */
+    if (b < n0) pmg::step_env<0, 8, false, true>(P, actions, P.sched[2 + b]);
+    else pmgp::step_group(P, actions, 2 * (b - n0) + ((int)threadIdx.x >> 6));
 }
 /* envs the packed path gave up on (a finger reached the table although the plan said it would not) */
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo(pmg::EnvParams P, const float* __restrict__ actions)
@@ -277,7 +305,10 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         return hipGetLastError();
     }
     if (P.nb == 0 && packed) {
-        hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs), dim3(64), 0, s, P, d_actions); /* n_prone + ceil(n_free/4) <= N */
+        /* the one-wavefront kernel FIRST: when it is its turn (a contact-free step) its 1024 wavefronts are placed on an
+         * empty machine, one per SIMD; behind the other kernel's draining empty workgroups they were not (0.82 ms) */
+        hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs), dim3(64), 0, s, P, d_actions, packed == 2 ? 1 : 0);  /* n_prone + ceil(n_free / 4) <= N */
+        if (packed == 2) hipLaunchKernelGGL(pmg_k_step_reach2, dim3(P.n_envs), dim3(128), 0, s, P, d_actions);   /* n_prone + ceil(n_free / 8) <= N */
         /* mispredictions are rare; surplus workgroups of the redo grid exit on their first instruction */
         hipLaunchKernelGGL(pmg_k_redo, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     } else if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);

@@ -27,7 +27,7 @@ __device__ __forceinline__ void store(unsigned int v, unsigned int* p) { __built
 namespace wv {
 
 constexpr int LANES = 64; /* lanes that cooperate on one env */
-__device__ __forceinline__ int lane() { return (int)threadIdx.x; }
+__device__ __forceinline__ int lane() { return (int)threadIdx.x & 63; }   /* (two-wave workgroups: the helper wavefront's lanes) */
 
 /* wave-level LDS ordering.  A workgroup is ONE wavefront and the LDS unit executes a wavefront's DS instructions in
  * program order, so a later read sees an earlier write of any lane: all that is needed is to stop the COMPILER from
@@ -224,7 +224,7 @@ namespace wr {
 
 constexpr int LANES = 16; /* lanes that cooperate on one env */
 __device__ __forceinline__ int lane() { return (int)threadIdx.x & 15; }
-__device__ __forceinline__ int row() { return (int)threadIdx.x >> 4; }
+__device__ __forceinline__ int row() { return ((int)threadIdx.x >> 4) & 3; }   /* (& 3: the second wavefront of a two-wave workgroup) */
 __device__ __forceinline__ void lds_sync() { wv::lds_sync(); }
 
 /* lane SRC (compile time) of the caller's row in every lane of the row: ONE DPP move (row_newbcast, gfx90a+), which the

@@ -17,15 +17,27 @@ ucontext_t g_sched;
 std::vector<Fiber> g_fibers;
 int g_cur = -1;
 const std::function<void()>* g_body = nullptr;
+int g_bar_gen = 0, g_bar_count = 0, g_live = 0;   /* workgroup barrier: generation, arrivals, live threads */
 
 void trampoline()
 {
     (*g_body)();
     g_fibers[g_cur].done = true;
+    g_live--;
+    if (g_live > 0 && g_bar_count >= g_live) { g_bar_count = 0; g_bar_gen++; }   /* the rest may be waiting for this one */
     swapcontext(&g_fibers[g_cur].ctx, &g_sched);
 }
 }  // namespace
 
+/* __syncthreads(): every LIVE thread of the workgroup has to arrive.  Wavefronts of one workgroup may run different code
+ * between two workgroup barriers (the helper wavefront of the two-wave step kernel), with different numbers of
+ * cross-lane yields in between: an arrived fiber keeps yielding until the last one is in. */
+void emu_block_barrier()
+{
+    const int gen = g_bar_gen;
+    if (++g_bar_count >= g_live) { g_bar_count = 0; g_bar_gen++; }
+    while (g_bar_gen == gen) emu_barrier();
+}
 void emu_barrier()
 {
     /* yield to the scheduler; it resumes this fiber after every other live
@@ -53,6 +65,7 @@ void emu::launch(int grid, int block, const std::function<void()>& body)
             f.ctx.uc_link = nullptr;
             makecontext(&f.ctx, (void (*)())trampoline, 0);
         }
+        g_live = block; g_bar_count = 0;
         bool alive = true;
         while (alive) {
             alive = false;

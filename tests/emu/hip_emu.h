@@ -40,8 +40,9 @@ extern emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 #define __launch_bounds__(...)
 #define __constant__ static const
 
-void emu_barrier();
-#define __syncthreads() emu_barrier()
+void emu_barrier();         /* wave-level: yield until every fiber has reached its next cross-lane point */
+void emu_block_barrier();   /* workgroup-level: every live thread arrives */
+#define __syncthreads() emu_block_barrier()
 
 /* exchange buffer for cross-lane primitives */
 extern float emu_xf[16 * 64 * 16]; /* [wave][slot][lane] */
