@@ -219,16 +219,25 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvP
 /* several free blocks (block_stack / block_rearrange): list 0 = envs whose gripper works on a block, with the full
  * 48-contact store; list 1 = the rest with a 30-contact store (20 KB of LDS instead of 29: 8 workgroups per CU instead
  * of 5).  The two launches run concurrently on two streams; a list-1 env that overflows is queued for the redo pass */
+#ifndef PMG_LIST_TWO_WAVES
+#define PMG_LIST_TWO_WAVES 1
+#endif
 constexpr int MULTI_SMALL_MAXC = 30;
+constexpr int LIST0_THREADS = PMG_LIST_TWO_WAVES ? 128 : 64;
+/* LIST 0 (the full contact store: the envs whose gripper works on an object -- the long pole of a batched step) runs
+ * with TWO wavefronts per workgroup: the second one collides while the first computes the dynamics (helper_wave_loop) */
+#ifndef PMG_LIST_TWO_WAVES
+#define PMG_LIST_TWO_WAVES 1
+#endif
 template <int NB, int MAXC, int LIST, int CYL = 0>
-__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(LIST == 0 && PMG_LIST_TWO_WAVES ? 128 : 64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmg::ContactLds<NB, MAXC> L;
     __shared__ pmg::LaneTabStore lcs;
     const int b = (int)blockIdx.x;
     if (b >= P.sched[LIST]) return;
     const int env = P.sched[2 + LIST * P.n_envs + b];
-    const bool ok = pmg::step_env_core<NB, MAXC, CYL>(P, actions, env, L, lcs, true);
+    const bool ok = pmg::step_env_core<NB, MAXC, CYL, LIST == 0 && PMG_LIST_TWO_WAVES>(P, actions, env, L, lcs, true);
     if (!ok && threadIdx.x == 0) {
         int* redo = P.sched + 2 + 2 * P.n_envs;
         int slot = atomicAdd(redo, 1);
@@ -257,8 +266,8 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
     if (P.chest >= 0 && packed) {
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
-        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
-        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
         (void)hipEventRecord(ev_join, side);
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
@@ -276,7 +285,7 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
     if (P.nb > 1 && packed) {
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
-        hipLaunchKernelGGL((pmg_k_step_list<5, 48, 0>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+        hipLaunchKernelGGL((pmg_k_step_list<5, 48, 0>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
         (void)hipEventRecord(ev_join, side);
         /* up to four blocks: 24 candidate pairs instead of 32 keep the narrowphase workspace under the row store (20 KB) */
         if (P.nb <= 4) hipLaunchKernelGGL((pmg_k_step_list<4, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
@@ -290,13 +299,13 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         const int groups = (P.n_envs + 3) / 4;
         if (P.task == PMG_TASK_SLIDE) {
-            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
             (void)hipEventRecord(ev_join, side);
             hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(64), 0, s, P, d_actions);
             (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         } else {
-            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(64), 0, side, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
             (void)hipEventRecord(ev_join, side);
             hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(64), 0, s, P, d_actions);
             (void)hipStreamWaitEvent(s, ev_join, 0);

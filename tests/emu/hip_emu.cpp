@@ -12,6 +12,7 @@ struct Fiber {
     ucontext_t ctx;
     char* stack = nullptr;
     bool done = false;
+    int wait_gen = -1;     /* >= 0: parked at the workgroup barrier of that generation (the scheduler skips it) */
 };
 ucontext_t g_sched;
 std::vector<Fiber> g_fibers;
@@ -36,7 +37,10 @@ void emu_block_barrier()
 {
     const int gen = g_bar_gen;
     if (++g_bar_count >= g_live) { g_bar_count = 0; g_bar_gen++; }
+    const int me = g_cur;
+    g_fibers[me].wait_gen = gen;
     while (g_bar_gen == gen) emu_barrier();
+    g_fibers[me].wait_gen = -1;
 }
 void emu_barrier()
 {
@@ -59,6 +63,7 @@ void emu::launch(int grid, int block, const std::function<void()>& body)
         for (int i = 0; i < block; i++) {
             Fiber& f = g_fibers[i];
             f.done = false;
+            f.wait_gen = -1;
             getcontext(&f.ctx);
             f.ctx.uc_stack.ss_sp = f.stack;
             f.ctx.uc_stack.ss_size = STACK_BYTES;
@@ -71,6 +76,7 @@ void emu::launch(int grid, int block, const std::function<void()>& body)
             alive = false;
             for (int i = 0; i < block; i++) {
                 if (g_fibers[i].done) continue;
+                if (g_fibers[i].wait_gen >= 0 && g_fibers[i].wait_gen == g_bar_gen) { alive = true; continue; }   /* parked */
                 g_cur = i;
                 threadIdx = {(unsigned)i, 0, 0};
                 swapcontext(&g_sched, &g_fibers[i].ctx);
