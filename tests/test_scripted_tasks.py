@@ -121,7 +121,7 @@ def test_emulated_grasp_and_lift_matches_oracle(emu_library):
             carried.append(t)
             return True
         return False
-    marked = _fly('pick_and_place', 2, 30, watch)
+    marked = _fly('pick_and_place', 2, 30, watch)   # (two envs: one goal on the table, one in the air)
     assert 4 <= len(marked) <= 8 and len(carried) == 2
     env = _quiet_env('pick_and_place', emu_library, 2, max_episode_steps=30)
     env.reset()
