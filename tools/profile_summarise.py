@@ -6,7 +6,7 @@ import json
 import os
 import sys
 
-task, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'r02')
+task, tag = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'r03')
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, 'gpurun_out', 'prof_' + task)

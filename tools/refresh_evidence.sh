@@ -4,7 +4,7 @@
 # gpurun_out/evidence/ with the names used in profiles/; copy it over with `cp gpurun_out/evidence/* profiles/`.
 #   tools/refresh_evidence.sh [round-tag] [tasks...]
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
@@ -31,12 +31,30 @@ done
 python bench.py --task pick_and_place --envs-per-gpu 8192 --dense-reward --steps 100 --warmup 10 > $out/${tag}_bench_pick_and_place8192_dense.json 2>/dev/null
 python bench.py --task pick_and_place --envs-per-gpu 8192 --steps 100 --warmup 10 --no-cpu-baseline > $out/${tag}_bench_pick_and_place8192_binary.json 2>/dev/null
 python bench.py --episode-steps 10 --no-cpu-baseline --no-extras > $out/${tag}_bench_reach4096_short_episodes.json 2>/dev/null
+python bench.py --lockstep --no-cpu-baseline > $out/${tag}_bench_reach4096_lockstep.json 2>/dev/null
+PMG_REACH_TWO_WAVES=0 python bench.py --no-cpu-baseline --no-extras > $out/${tag}_bench_reach4096_one_wave_workgroups.json 2>/dev/null
+bash tools/bench_all.sh > $out/${tag}_bench_all_tasks_staggered_and_lockstep.txt 2>&1
 PMG_PACKED=0 python bench.py --no-cpu-baseline --no-extras > $out/${tag}_bench_reach4096_one_env_per_wave.json 2>/dev/null
-for n in 8192 16384 32768 65536; do
+for n in 8192 16384 32768 65536 131072; do
   python bench.py --envs-per-gpu $n --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $out/${tag}_bench_reach${n}.json 2>/dev/null
 done
 PMG_BENCH_FORCE_DIST=1 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $out/${tag}_bench_reach4096_one_rank_rccl_path.json 2>/dev/null
+# 3b. scripted-policy evidence: solvability on device and oracle, teacher-forced parity along the scripted trajectories
+bash tools/batch_scripted.sh 256 > $out/${tag}_scripted_batch.log 2>&1
+cp gpurun_out/scripted/suite.jsonl $out/${tag}_scripted_suite.jsonl 2>/dev/null
+python - <<'PY' > $out/${tag}_scripted_teacher_forced.json
+import json, glob, os
+out = {}
+for f in sorted(glob.glob('gpurun_out/scripted/tf_*.json')):
+    try:
+        d = json.load(open(f))
+    except Exception:
+        continue
+    out[os.path.basename(f)[3:-5]] = {k: d[k] for k in ('task', 'who', 'policy', 'N', 'T', 'flag_mismatches', 'flags_off_threshold', 'final_success', 'schedule_env_steps', 'stats')}
+print(json.dumps(out, indent=1))
+PY
 # 4. rocprofv3 --kernel-trace --stats of the DEFAULT command (the one the driver's line comes from)
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_default -- python $root/bench.py --no-cpu-baseline > /dev/null 2>&1 )
 cp $root/gpurun_out/prof_default/*/*_kernel_stats.csv $out/${tag}_reach4096_default_command_kernel_stats.csv 2>/dev/null
+python tools/resource_table.py > $out/${tag}_kernel_resources.txt 2>/dev/null
 ls $out | wc -l
