@@ -353,7 +353,9 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         e->P.wave_budget = 6 * cus;
         /* measured on chest_push-4 / chest_pick_and_place-4 x 4096 (tools/chest_exp.sh): 6.5 cm / 6.4 cm put 40-65 % of a
          * random-policy batch on the full-layout list (0.337 M); 5 cm / 2 cm: 20 %, no redo, 0.388 / 0.416 M */
-        e->P.near_r = e->P.chest >= 0 ? 0.05f : 0.065f;
+        /* block_stack-4 (tools/near_exp.sh): 6.5 cm puts up to 8 % of the batch on the full-store list, 4.5 cm 1.5 %, no redo
+         * either way: 0.549 -> 0.566 M; the one-object tasks are insensitive (0.04 starts to redo) */
+        e->P.near_r = e->P.chest >= 0 ? 0.05f : (e->nb > 1 ? 0.045f : 0.065f);
         e->P.chest_reach = 0.02f;
         if (const char* nr = getenv("PMG_NEAR_R")) e->P.near_r = (float)atof(nr);   /* (tuning experiments) */
         if (const char* cr = getenv("PMG_CHEST_REACH")) e->P.chest_reach = (float)atof(cr);
