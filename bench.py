@@ -343,7 +343,7 @@ def main():
                          'traffic': traffic if (traffic_src == src_hash) else None,
                          'traffic_source': {'file': traffic_file, 'profiled_kernel_sources': traffic_src, 'running_kernel_sources': src_hash,
                                             'match': traffic_src == src_hash},
-                         'kernel': 'pmg_k_step_reach (+ pmg_k_redo)' if args.task == 'reach' else 'pmg_k_step<NB,MAXC,CYL> family',
+                         'kernel': 'pmg_k_step_reach2 / pmg_k_step_reach (the device picks one per step, DESIGN.md 3.1f) + pmg_k_redo' if args.task == 'reach' else 'pmg_k_step_list / pmg_k_step_obj4 family (two concurrent launches + redo)',
                          'kernel_ms': kernel_ms, 'kernel_ms_min': kmin, 'kernel_ms_max': kmax, 'launches': launches,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES[args.task],
                          'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by construction '

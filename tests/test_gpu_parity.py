@@ -730,3 +730,34 @@ def test_sharded_push_agrees_with_the_unsharded_batch_to_float32_tolerance(built
     print('sharded vs unsharded push, tip + block position after %d steps: max %.2e median %.2e, beyond 1e-4: %d of %d' % (T, err.max(), np.median(err), (err > 1e-4).sum(), N))
     assert np.median(err) < 1e-5 and (err > 1e-3).mean() <= 0.01
     full.close(), lo.close(), hi.close()
+
+
+def test_two_wavefront_reach_kernel_is_bit_identical_to_the_one_wavefront_kernel(built):
+    """pmg_k_step_reach2 (the helper wavefront collides beside the dynamics; eight contact-free envs per workgroup) and
+    pmg_k_step_reach (PMG_REACH_TWO_WAVES=0) run the same functions on the same data: after 40 steps that drive a good
+    part of the batch onto the table the state rows and the packed outputs must be EQUAL, bit for bit."""
+    import os
+    N = 2048
+
+    def make(two):
+        os.environ['PMG_REACH_TWO_WAVES'] = two
+        try:
+            return pmg.make_env(task='reach', num_envs=N, seed=21, seed_stride=1)
+        finally:
+            del os.environ['PMG_REACH_TWO_WAVES']
+    a2, a1 = make('1'), make('0')
+    a2.reset(), a1.reset()
+    rs = np.random.RandomState(8)
+    touched = 0
+    for t in range(40):
+        a = rs.uniform(-1, 1, (N, 3)).astype(np.float32)
+        a[:, 2] = -np.abs(a[:, 2])
+        o2, r2, d2, i2 = a2.step(a)
+        o1, r1, d1, i1 = a1.step(a)
+        touched = max(touched, len(a2.handle.schedule()['prone']))
+        for k in o2:
+            assert np.array_equal(o2[k], o1[k]), (t, k)
+        assert np.array_equal(r2, r1) and np.array_equal(i2['goal_achieved'], i1['goal_achieved'])
+    assert touched > N // 4                                   # the two-wave workgroups did carry those steps
+    assert np.array_equal(a2.get_state(), a1.get_state())
+    a2.close(), a1.close()
