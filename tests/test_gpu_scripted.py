@@ -30,16 +30,17 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 
 pytestmark = pytest.mark.gpu
 
-# "ever succeeded" bars: (all envs, kinematically feasible envs) -- as tests/test_scripted_tasks.py; device / oracle
-# rates measured on 256 envs in the comments
+# "ever succeeded" bars over ALL 256 envs / over the envs whose object starts where the arm gets behind it at once
+# (scripted_suite.feasible_mask) -- the review's 95 % for every task but slide; oracle rates measured on the same seeds in
+# the comments (the device's are within 1-2 envs of them, printed by the test)
 BARS = {
-    'reach': (1.0, 1.0),                     # 1.000 / 1.000
-    'pick_and_place': (0.95, 0.95),          # 0.984 / 0.984
-    'push': (0.75, 0.95),                    # 0.844 / 0.852; feasible 1.000 / 1.000
-    'block_stack_2': (0.90, 0.90),           # 0.977 / 0.977
-    'block_stack_4': (0.80, 0.80),           # 0.895 / 0.902
-    'chest_push': (0.60, 0.95),              # 0.672 / 0.688; feasible 1.000 / 1.000
-    'chest_pick_and_place': (0.95, 0.95),    # 0.977 / 0.977
+    'reach': (1.0, 1.0),                     # 1.000
+    'pick_and_place': (0.95, 0.95),          # 1.000
+    'push': (0.95, 0.97),                    # 0.992; feasible 1.000
+    'block_stack_2': (0.95, 0.95),           # 0.980
+    'block_stack_4': (0.95, 0.95),           # 0.977
+    'chest_push': (0.93, 0.97),              # 0.957; feasible 1.000
+    'chest_pick_and_place': (0.95, 0.95),    # 1.000
 }
 
 
@@ -63,13 +64,13 @@ def test_device_solves_the_task_with_the_scripted_policy(built, name):
 TEACHER = {
     'pick_and_place': ({}, 60, {'tip_pos': (1e-4, 2e-4), 'block_pos': (3e-4, 1e-3), 'q_arm': (2e-4, 5e-4)}),
     # tip 2.7e-5 / 4.9e-5, block 9.5e-5 / 2.3e-4 (1 vs 3 outliers), q_arm 5.7e-5 / 1.0e-4 (1 vs 2)
-    'push': ({}, 100, {'tip_pos': (2e-5, 1e-4), 'block_pos': (1e-4, 5e-4), 'q_arm': (5e-5, 2e-4)}),
+    'push': ({}, 300, {'tip_pos': (2e-5, 1e-4), 'block_pos': (1e-4, 5e-4), 'q_arm': (5e-5, 2e-4)}),
     # tip 1.3e-6 / 5.1e-6, block 8.2e-6 / 4.6e-5 (4 vs 31), q_arm 4.7e-6 / 1.6e-5 (0 vs 5)
     'slide': ({}, 60, {'tip_pos': (2e-5, 5e-4), 'block_pos': (1e-4, 2e-3), 'q_arm': (5e-5, 2e-3)}),
     # tip 1.1e-6 / 1.3e-4 (2 vs 2), block 1.1e-5 / 6.4e-4 (12 vs 15), q_arm 3.0e-6 / 5.5e-4 (11 vs 13)
-    'block_stack': ({'num_block': 4}, 300, {'tip_pos': (1e-4, 2e-4), 'block_pos': (2e-4, 5e-4), 'q_arm': (1e-4, 4e-4)}),
+    'block_stack': ({'num_block': 4}, 340, {'tip_pos': (1e-4, 2e-4), 'block_pos': (2e-4, 5e-4), 'q_arm': (1e-4, 4e-4)}),
     # tip 1.4e-5 / 4.5e-5 (0 vs 0), block 4.9e-5 / 1.4e-4 (5 vs 31), q_arm 2.7e-5 / 1.0e-4 (3 vs 31)
-    'chest_push': ({'num_block': 1}, 160, {'tip_pos': (2e-5, 2e-4), 'block_pos': (5e-4, 2e-3), 'q_arm': (1e-4, 1e-3), 'door_q': (2e-5, 1e-4)}),
+    'chest_push': ({'num_block': 1}, 360, {'tip_pos': (2e-5, 2e-4), 'block_pos': (5e-4, 2e-3), 'q_arm': (1e-4, 1e-3), 'door_q': (2e-5, 1e-4)}),
     # tip 2.7e-6 / 4.8e-5 (3 vs 2), block 1.2e-4 / 7.0e-4 (22 vs 82), q_arm 1.3e-5 / 2.6e-4 (8 vs 28), door 6.8e-7 / 7.0e-6
     'chest_pick_and_place': ({'num_block': 1}, 100, {'tip_pos': (1e-4, 2e-4), 'block_pos': (2e-4, 5e-4), 'q_arm': (1e-4, 3e-4), 'door_q': (2e-5, 1e-4)}),
     # tip 1.5e-5 / 3.7e-5 (0 vs 0), block 4.9e-5 / 1.1e-4 (3 vs 4), q_arm 2.7e-5 / 6.8e-5 (1 vs 3), door 7.6e-7 / 3.3e-6

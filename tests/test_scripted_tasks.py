@@ -26,17 +26,18 @@ sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import scripted_policies as SP  # noqa: E402
 import scripted_suite as SS     # noqa: E402
 
-# task -> (bar on "ever succeeded" over all envs, bar over the kinematically feasible envs); measured (64 envs, seeds
-# 0..63, float64 oracle) in the comments.  Where the two differ the difference is the part of the object box the arm
-# cannot get BEHIND (scripted_suite.feasible_mask): a push towards the robot needs the tip on the far side of the block.
+# task -> (bar on "ever succeeded" over all envs, bar over the envs whose object starts where the arm gets behind it at
+# once (scripted_suite.feasible_mask)); measured (64 / 256 envs, float64 oracle) in the comments.  Since the far-edge
+# detour of the push legs, the off-centre grasp and the staging of far-edge blocks (tools/scripted_policies.py) every task
+# but slide is solved for >= 95 % of ALL envs at 256 envs; the 64-env bars sit one or two envs under the measured rates.
 BARS = {
-    'reach': (1.0, 1.0),                     # 1.000
-    'pick_and_place': (0.95, 0.95),          # 0.984 (the rest: blocks at the far edge of the tip box)
-    'push': (0.75, 0.95),                    # 0.812 / 1.000
-    'block_stack_2': (0.90, 0.90),           # 0.969
-    'block_stack_4': (0.80, 0.80),           # 0.922 (ever) / 0.875 (at step 300): a four-high tower creeps, see DESIGN.md
-    'chest_push': (0.72, 0.95),              # 0.781 / 1.000
-    'chest_pick_and_place': (0.95, 0.95),    # 1.000
+    'reach': (1.0, 1.0),                     # 1.000 / 1.000
+    'pick_and_place': (0.97, 0.97),          # 1.000 / 1.000
+    'push': (0.95, 0.97),                    # 0.984 / 0.992 (feasible 1.000)
+    'block_stack_2': (0.95, 0.95),           # 1.000 / 0.980
+    'block_stack_4': (0.92, 0.92),           # 0.969 / 0.977 (ever; 0.86-0.89 still standing at step 340: a four-high tower creeps)
+    'chest_push': (0.90, 0.97),              # 0.938 / 0.957 (feasible 1.000)
+    'chest_pick_and_place': (0.97, 0.97),    # 1.000 / 1.000
 }
 
 

@@ -22,6 +22,7 @@ import numpy as np
 STEP = 0.01            # tip-target travel per unit action (kuka.py:209)
 TABLE_Z = 0.175        # block centre resting on the table = lower tip clip (kuka.py:40)
 CHEST_CENTRE = np.array([-0.65, 0.0, 0.175])
+GRASP_X = -0.412       # grasp points stay behind this x (see _PickPlaceCore)
 SAFE_X = -0.415        # carry / place targets stay behind this x: beyond it the arm is nearly stretched and the DLS IK creeps
 TIP_LOW, TIP_HIGH = np.array([-0.67, -0.20, 0.175]), np.array([-0.37, 0.20, 0.55])   # kuka.py:40-41
 
@@ -80,18 +81,22 @@ class _PickPlaceCore:
         target = target.copy()
         if clamp_x:
             target[:, 0] = np.minimum(target[:, 0], SAFE_X)    # the arm's IK misbehaves at the far edge of the tip box
-        lost = idx & (ph >= 3) & (ph <= 5) & (np.abs(blk - tip).max(1) > 0.03)
+        lost = idx & (ph >= 3) & (ph <= 5) & (np.abs(blk - tip).max(1) > 0.035)
         pol._set_phase(lost, 0)                                # dropped the block: grasp it again
-        above = blk + np.array([0, 0, self.clearance])
+        # the grasp point: the block's centre, but not beyond where the arm gets quickly (GRASP_X: the fingers are 2.5 cm
+        # wide in x, a block at the far edge of the object box is gripped up to 1.2 cm off-centre)
+        grasp = blk.copy()
+        grasp[:, 0] = np.minimum(grasp[:, 0], GRASP_X)
+        above = grasp + np.array([0, 0, self.clearance])
         if fly_z is not None:                                  # fly over everything that stands on the table
             above[:, 2] = np.maximum(above[:, 2], fly_z)
         m = idx & (ph == 0)
         e[m] = (above - tip)[m]
-        arrived = m & (np.abs(blk[:, :2] - tip[:, :2]).max(1) < 0.006)
+        arrived = m & (np.abs(grasp[:, :2] - tip[:, :2]).max(1) < 0.006)
         pol._set_phase(arrived, 1)
         m = idx & (ph == 1)
-        e[m] = (blk - tip)[m]
-        arrived = m & (np.abs(blk - tip).max(1) < 0.006)
+        e[m] = (grasp - tip)[m]
+        arrived = m & (np.abs(grasp - tip).max(1) < 0.006)
         pol._set_phase(arrived, 2)
         m = idx & (ph == 2)
         grip[m] = 1.0
@@ -158,10 +163,20 @@ class PushPolicy(Policy):
     error first; a leg whose error is under `skip` is left out).  Per leg: rise, fly behind the block, come down, push.
     phases: 0 pick the leg - 1 rise / fly - 2 descend - 3 push."""
 
-    def __init__(self, n, standoff=0.042, fly_z=0.222, ground_z=0.177, skip=0.02, tol=0.006):
+    def __init__(self, n, standoff=0.042, fly_z=0.222, ground_z=0.177, skip=0.02, tol=0.006, side_y=0.15):
         super().__init__(n)
         self.standoff, self.fly_z, self.ground_z, self.skip, self.tol = standoff, fly_z, ground_z, skip, tol
         self.axis = np.zeros(n, np.int32)
+        # far edge of the tip box: the arm cannot get behind a block at x > -0.43 near the centre line (the IK creeps; it
+        # reaches x = -0.378 only at |y| >= 0.15).  A fly phase that stalls there triggers a detour: push the block
+        # sideways to |y| = side_y first (stage 1), then towards the robot with a short stand-off (stage 2)
+        self.side_y = side_y
+        self.detour = np.zeros(n, np.int32)
+        self.side = np.ones(n)
+
+    def reset(self, mask=None):
+        super().reset(mask)
+        self.detour[slice(None) if mask is None else np.asarray(mask, bool)] = 0
 
     def _act(self, obs, a):
         ob = obs['observation']
@@ -176,6 +191,16 @@ class PushPolicy(Policy):
         err = goal[:, :2] - blk[:, :2]
         finished = idx & (np.abs(err).max(1) < self.skip)
         ph = self.phase
+        # the detour's own targets: stage 1 = sideways to side * side_y, stage 2 = the x error alone
+        d1, d2 = self.detour == 1, self.detour == 2
+        err[d1, 0] = 0.0
+        err[d1, 1] = (self.side * self.side_y - blk[:, 1])[d1]
+        self.detour[d1 & (np.abs(err[:, 1]) < 0.012)] = 2
+        d1, d2 = self.detour == 1, self.detour == 2
+        err[d2, 0] = (goal[:, 0] - blk[:, 0])[d2]
+        err[d2, 1] = 0.0
+        self.detour[d2 & ((np.abs(err[:, 0]) < self.tol + 0.004) | (blk[:, 0] < -0.47))] = 0   # back where the arm gets behind it anywhere
+        finished &= self.detour == 0
         m = idx & (ph == 0) & ~finished
         self.axis[m] = np.argmax(np.abs(err), axis=1)[m]
         self._set_phase(m, 1)
@@ -183,7 +208,7 @@ class PushPolicy(Policy):
         sgn = np.sign(err[rows, k])
         sgn[sgn == 0] = 1.0
         behind = blk[:, :2].copy()
-        behind[rows, k] -= sgn * self.standoff
+        behind[rows, k] -= sgn * np.where(self.detour == 2, 0.034, self.standoff)
         behind = np.clip(behind, TIP_LOW[:2] + 0.004, TIP_HIGH[:2] - 0.004)   # the tip target is clipped to this box (kuka.py:40-41)
         e = np.zeros((n, 3))
         m = idx & (ph == 1) & ~finished              # rise, then fly
@@ -194,7 +219,12 @@ class PushPolicy(Policy):
         tgt[crossing, :2] = tip[crossing, :2]
         already = (np.abs(behind - tip[:, :2]).max(1) < 0.012) & low    # e.g. the second leg starts where it stands
         e[m] = (tgt - tip)[m]
-        self._set_phase(m & ((np.abs(behind - tip[:, :2]).max(1) < 0.005) | already), 2)
+        self.count[m] += 1
+        stalled = m & (self.count > 35) & (self.detour == 0) & (k == 0) & (sgn < 0) & (blk[:, 0] > -0.45)
+        self.detour[stalled] = 1
+        self.side[stalled] = np.where(blk[stalled, 1] >= 0, 1.0, -1.0)
+        self._set_phase(stalled, 0)
+        self._set_phase(m & ~stalled & ((np.abs(behind - tip[:, :2]).max(1) < 0.005) | already), 2)
         m = idx & (ph == 2) & ~finished              # descend
         tgt = np.concatenate([behind, np.full((n, 1), self.ground_z)], 1)
         e[m] = (tgt - tip)[m]
@@ -207,7 +237,7 @@ class PushPolicy(Policy):
         e[m, :2] = v[m]
         e[m, 2] = (self.ground_z - tip[:, 2])[m]
         leg_done = m & (np.abs(err[rows, k]) < self.tol)
-        slipped = m & (np.abs(blk[rows, other] - tip[rows, other]) > 0.02)
+        slipped = m & ((np.abs(blk[rows, other] - tip[rows, other]) > 0.02) | ((tip[rows, k] - blk[rows, k]) * sgn > 0.0))   # beside / past the block
         self._set_phase(leg_done | slipped, 0)
         a[idx, :3] = np.clip(e[idx] / STEP, -1, 1)
         a[finished, :3] = 0.0
@@ -233,10 +263,13 @@ class StackPolicy(Policy):
         self.nb, self.tol = num_block, tol
         self.core = _PickPlaceCore(n)
         self.cur = np.zeros(n, np.int32)           # position in the stacking order
+        self.staging = np.zeros(n, bool)           # pulling a far-edge block in before it is stacked
 
     def reset(self, mask=None):
         super().reset(mask)
-        self.cur[slice(None) if mask is None else np.asarray(mask, bool)] = 0
+        m = slice(None) if mask is None else np.asarray(mask, bool)
+        self.cur[m] = 0
+        self.staging[m] = False
 
     def _act(self, obs, a):
         n, nb = self.n, self.nb
@@ -265,6 +298,21 @@ class StackPolicy(Policy):
         active = self.cur < nb
         k = np.minimum(self.cur, nb - 1)
         b, place = place_of(k)
+        # a block at the far edge of the object box can only be gripped off-centre (GRASP_X), and set down on another block
+        # like that its overhanging fingers shove the tower: pull it in first -- put it on the table 6 cm closer, at a free
+        # spot, and pick it up again, centred
+        mine = blocks[rows, b]
+        far = active & (mine[:, 0] > GRASP_X + 0.002) & (self.phase == 0)
+        self.staging[far] = True
+        self.staging[self.staging & (mine[:, 0] <= GRASP_X + 0.002) & (self.phase == 0)] = False
+        if self.staging.any():
+            spot = np.stack([np.full(n, -0.47), mine[:, 1], np.full(n, TABLE_Z)], 1)
+            for _ in range(3):                     # slide the spot along y away from the other blocks
+                d = blocks[:, :, :2] - spot[:, None, :2]
+                d[rows, b] = 9.0
+                near = np.linalg.norm(d, axis=2).min(1) < 0.055
+                spot[near, 1] += np.where(spot[near, 1] > 0, -0.06, 0.06)
+            place[self.staging] = spot[self.staging]
         # carry height: the carried block's underside clears whatever stands at the target (and the blocks on the table)
         travel = np.maximum(place[:, 2], TABLE_Z) + 0.045
         fly = blocks[:, :, 2].max(1) + 0.065
@@ -327,11 +375,12 @@ class ChestPushPolicy(Policy):
             goal[:, 0] += 0.03 * k                     # later blocks stop behind the earlier ones
             off_line = np.abs(blk[:, 1] - goal[:, 1]) > 0.012
             outside = blk[:, 0] > -0.585               # still in front of the doorway
-            goal[off_line & outside, 0] = blk[off_line & outside, 0]      # first to the centre line, only then in
+            hold = off_line & outside & (self.push.detour == 0)       # (a far-edge detour of the push legs has its own targets)
+            goal[hold, 0] = blk[hold, 0]                              # first to the centre line, only then in
             act = pushing & (self.cur < nb)
             pa = np.zeros((n, 3), np.float32)
             fin = self.push.push_step(act, tip, blk, goal, pa)
-            fin &= ~(off_line & outside)
+            fin &= ~(off_line & outside) & (self.push.detour == 0)
             a[act] = pa[act]
             self.cur[fin] += 1
             self.push.phase[fin] = 0

@@ -20,11 +20,11 @@ import scripted_policies as SP  # noqa: E402
 SUITE = {
     'reach': ({}, 50),
     'pick_and_place': ({}, 50),
-    'push': ({}, 100),
+    'push': ({}, 300),
     'slide': ({}, 60),
     'block_stack_2': ({'num_block': 2}, 130),
-    'block_stack_4': ({'num_block': 4}, 300),
-    'chest_push': ({'num_block': 1}, 160),
+    'block_stack_4': ({'num_block': 4}, 340),
+    'chest_push': ({'num_block': 1}, 360),
     'chest_pick_and_place': ({'num_block': 1}, 100),
 }
 
