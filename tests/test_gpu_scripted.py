@@ -63,17 +63,19 @@ def test_device_solves_the_task_with_the_scripted_policy(built, name):
 # float32 oracle) in the comments
 TEACHER = {
     'pick_and_place': ({}, 60, {'tip_pos': (1e-4, 2e-4), 'block_pos': (3e-4, 1e-3), 'q_arm': (2e-4, 5e-4)}),
-    # tip 2.7e-5 / 4.9e-5, block 9.5e-5 / 2.3e-4 (1 vs 3 outliers), q_arm 5.7e-5 / 1.0e-4 (1 vs 2)
-    'push': ({}, 300, {'tip_pos': (2e-5, 1e-4), 'block_pos': (1e-4, 5e-4), 'q_arm': (5e-5, 2e-4)}),
-    # tip 1.3e-6 / 5.1e-6, block 8.2e-6 / 4.6e-5 (4 vs 31), q_arm 4.7e-6 / 1.6e-5 (0 vs 5)
+    # tip 2.7e-5 / 5.0e-5, block 9.5e-5 / 2.3e-4, q_arm 5.7e-5 / 1.1e-4; outliers 0 vs 0 (float32 oracle p99: 1.2e-4 / 1.4e-4 / 3.4e-4)
+    'push': ({}, 300, {'tip_pos': (2e-5, 1e-4), 'block_pos': (1e-4, 1e-3), 'q_arm': (5e-5, 2e-4)}),
+    # tip 3.3e-6 / 6.5e-6, block 6.6e-6 / 2.4e-4 (4 vs 33), q_arm 6.4e-6 / 1.4e-5 (0 vs 10); incl. the far-edge detours
     'slide': ({}, 60, {'tip_pos': (2e-5, 5e-4), 'block_pos': (1e-4, 2e-3), 'q_arm': (5e-5, 2e-3)}),
-    # tip 1.1e-6 / 1.3e-4 (2 vs 2), block 1.1e-5 / 6.4e-4 (12 vs 15), q_arm 3.0e-6 / 5.5e-4 (11 vs 13)
+    # tip 1.1e-6 / 1.3e-4 (2 vs 2), block 1.1e-5 / 6.4e-4 (12 vs 15), q_arm 2.9e-6 / 5.5e-4 (11 vs 13)
     'block_stack': ({'num_block': 4}, 340, {'tip_pos': (1e-4, 2e-4), 'block_pos': (2e-4, 5e-4), 'q_arm': (1e-4, 4e-4)}),
-    # tip 1.4e-5 / 4.5e-5 (0 vs 0), block 4.9e-5 / 1.4e-4 (5 vs 31), q_arm 2.7e-5 / 1.0e-4 (3 vs 31)
-    'chest_push': ({'num_block': 1}, 360, {'tip_pos': (2e-5, 2e-4), 'block_pos': (5e-4, 2e-3), 'q_arm': (1e-4, 1e-3), 'door_q': (2e-5, 1e-4)}),
-    # tip 2.7e-6 / 4.8e-5 (3 vs 2), block 1.2e-4 / 7.0e-4 (22 vs 82), q_arm 1.3e-5 / 2.6e-4 (8 vs 28), door 6.8e-7 / 7.0e-6
+    # tip 1.3e-5 / 3.7e-5 (0 vs 1), blocks 5.1e-5 / 1.5e-4 (0 vs 10), q_arm 2.5e-5 / 8.1e-5 (0 vs 7)
+    'chest_push': ({'num_block': 1}, 360, {'tip_pos': (5e-5, 1.5e-3), 'block_pos': (5e-4, 2e-3), 'q_arm': (3e-4, 5e-3), 'door_q': (2e-5, 1e-3)}),
+    # the far-edge detours put the arm at the limit of its reach for dozens of steps (wild, stiff dynamics in BOTH float32
+    # builds): tip 2.5e-5 / 6.5e-4 (40 vs 59), block 2.4e-4 / 6.3e-4 (55 vs 154), q_arm 1.4e-4 / 2.2e-3 (276 vs 739),
+    # door 5.6e-6 / 3.8e-4 (24 vs 34); float32 oracle p99: 1.9e-4 / 2.4e-4 / 8.2e-4 / 3.6e-5
     'chest_pick_and_place': ({'num_block': 1}, 100, {'tip_pos': (1e-4, 2e-4), 'block_pos': (2e-4, 5e-4), 'q_arm': (1e-4, 3e-4), 'door_q': (2e-5, 1e-4)}),
-    # tip 1.5e-5 / 3.7e-5 (0 vs 0), block 4.9e-5 / 1.1e-4 (3 vs 4), q_arm 2.7e-5 / 6.8e-5 (1 vs 3), door 7.6e-7 / 3.3e-6
+    # tip 1.4e-5 / 3.6e-5, block 4.7e-5 / 1.1e-4, q_arm 2.4e-5 / 6.3e-5, door 7.6e-7 / 3.3e-6; outliers 0 vs 0
 }
 
 
