@@ -346,7 +346,7 @@ def test_narrowphase_distance_agrees_with_closest_point_solver(built, shape, til
     r, hl = 0.03, 0.01
     frac_bar, worst_bar, miss_bar = REGIMES[(shape, tilt)]
     errs, missed = [], 0
-    for trial in range(110):
+    for trial in range(70):
         if tilt is None:
             Ra, Rb = _rand_rot(rs), _rand_rot(rs)
         else:
@@ -359,15 +359,15 @@ def test_narrowphase_distance_agrees_with_closest_point_solver(built, shape, til
         sa = (r, hl) if shape == 'cyl' else ha
         want = rs.uniform(2e-4, 1.8e-3)          # slide A along u until the true gap is the wanted one
         lo, hi = 0.0, 0.2
-        for _ in range(50):
+        for _ in range(30):
             mid = 0.5 * (lo + hi)
-            p, q = _closest_pair(cb + u * mid, Ra, sa, cb, Rb, hb, iters=300)
+            p, q = _closest_pair(cb + u * mid, Ra, sa, cb, Rb, hb, iters=150)
             if np.linalg.norm(p - q) > want:
                 hi = mid
             else:
                 lo = mid
         ca = cb + u * hi
-        p, q = _closest_pair(ca, Ra, sa, cb, Rb, hb, iters=6000)
+        p, q = _closest_pair(ca, Ra, sa, cb, Rb, hb, iters=4000)
         gap = np.linalg.norm(p - q)
         if not (1e-4 < gap < 1.95e-3):
             continue
@@ -379,6 +379,6 @@ def test_narrowphase_distance_agrees_with_closest_point_solver(built, shape, til
     errs = np.array(errs)
     print('%s x box, tilt %s: %d poses, distance - true gap: min %.2e max %.2e, beyond 1e-5: %d, beyond 1e-4: %d, missed: %d'
           % (shape, tilt, len(errs), errs.min(), errs.max(), (np.abs(errs) > 1e-5).sum(), (np.abs(errs) > 1e-4).sum(), missed))
-    assert len(errs) >= 90
+    assert len(errs) >= 55
     assert np.median(np.abs(errs)) < 1e-6                       # the typical pose: identical (to the solver's convergence)
     assert (np.abs(errs) > 1e-4).mean() <= frac_bar and np.abs(errs).max() <= worst_bar and missed <= miss_bar
