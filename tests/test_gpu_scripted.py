@@ -38,6 +38,7 @@ BARS = {
     'pick_and_place': (0.95, 0.95),          # 1.000
     'push': (0.95, 0.97),                    # 0.992; feasible 1.000
     'block_stack_2': (0.95, 0.95),           # 0.980
+    'block_rearrange_2': (0.84, 0.84),       # device 0.883 / oracle 0.895 (the other block is an obstacle nobody plans around)
     'block_stack_4': (0.95, 0.95),           # 0.977
     'chest_push': (0.93, 0.97),              # 0.957; feasible 1.000
     'chest_pick_and_place': (0.95, 0.95),    # 1.000
@@ -70,6 +71,8 @@ TEACHER = {
     # tip 1.1e-6 / 1.3e-4 (2 vs 2), block 1.1e-5 / 6.4e-4 (12 vs 15), q_arm 2.9e-6 / 5.5e-4 (11 vs 13)
     'block_stack': ({'num_block': 4}, 340, {'tip_pos': (1e-4, 2e-4), 'block_pos': (2e-4, 5e-4), 'q_arm': (1e-4, 4e-4)}),
     # tip 1.3e-5 / 3.7e-5 (0 vs 1), blocks 5.1e-5 / 1.5e-4 (0 vs 10), q_arm 2.5e-5 / 8.1e-5 (0 vs 7)
+    'block_rearrange': ({'num_block': 2}, 400, {'tip_pos': (5e-5, 5e-4), 'block_pos': (5e-4, 2e-3), 'q_arm': (1e-4, 1e-3)}),
+    # tip 3.2e-6 / 8.2e-5 (7 vs 16), blocks 2.3e-4 / 3.6e-4 (57 vs 146: blocks shoved into each other), q_arm 7.8e-6 / 2.8e-4 (32 vs 142)
     'chest_push': ({'num_block': 1}, 360, {'tip_pos': (5e-5, 1.5e-3), 'block_pos': (5e-4, 2e-3), 'q_arm': (3e-4, 5e-3), 'door_q': (2e-5, 1e-3)}),
     # the far-edge detours put the arm at the limit of its reach for dozens of steps (wild, stiff dynamics in BOTH float32
     # builds): tip 2.5e-5 / 6.5e-4 (40 vs 59), block 2.4e-4 / 6.3e-4 (55 vs 154), q_arm 1.4e-4 / 2.2e-3 (276 vs 739),

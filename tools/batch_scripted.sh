@@ -4,8 +4,8 @@
 mkdir -p gpurun_out/scripted
 N=${1:-256}
 python tools/scripted_suite.py both $N > gpurun_out/scripted/suite.jsonl 2> gpurun_out/scripted/suite.err
-for t in pick_and_place push slide block_stack chest_push chest_pick_and_place; do
-  T=60; [ $t = push ] && T=300; [ $t = block_stack ] && T=340; [ $t = chest_push ] && T=360; [ $t = chest_pick_and_place ] && T=100
+for t in pick_and_place push slide block_stack block_rearrange chest_push chest_pick_and_place; do
+  T=60; [ $t = push ] && T=300; [ $t = block_stack ] && T=340; [ $t = block_rearrange ] && T=400; [ $t = chest_push ] && T=360; [ $t = chest_pick_and_place ] && T=100
   python tools/teacher_forced.py $t $N $T scripted > gpurun_out/scripted/tf_dev_$t.json 2> gpurun_out/scripted/tf_dev_$t.err
   python tools/teacher_forced.py $t $N $T f32 scripted > gpurun_out/scripted/tf_f32_$t.json 2> gpurun_out/scripted/tf_f32_$t.err
 done

@@ -451,11 +451,48 @@ class ChestPickAndPlacePolicy(Policy):
         a[idle, 3] = -1.0
 
 
+class RearrangePolicy(Policy):
+    """block_rearrange (kuka_multi_step_envs.py:151-227): closed gripper, every block is pushed to its target slot on the
+    table with the axis-aligned legs of PushPolicy, one block after the other (blocks already within `skip` of their slot
+    are left alone; the others are obstacles nobody plans around -- with two blocks that rarely matters)."""
+
+    def __init__(self, n, num_block=2):
+        super().__init__(n)
+        self.nb = num_block
+        self.push = PushPolicy(n, skip=0.015)
+        self.cur = np.zeros(n, np.int32)
+
+    def reset(self, mask=None):
+        super().reset(mask)
+        self.cur[slice(None) if mask is None else np.asarray(mask, bool)] = 0
+        self.push.reset(mask)
+
+    def _act(self, obs, a):
+        n, nb = self.n, self.nb
+        rows = np.arange(n)
+        tip, _, blocks = multi_block_views(obs, nb)
+        targets = obs['desired_goal'].astype(np.float64)[:, :3 * nb].reshape(n, nb, 3)
+        err = np.abs(targets[:, :, :2] - blocks[:, :, :2]).max(2)
+        todo = err >= self.push.skip
+        # keep working on the current block until it is there, then the next one that is not
+        k = np.minimum(self.cur, nb - 1)
+        switch = (~todo[rows, k]) & (self.push.phase == 0) | (self.cur >= nb)
+        nxt = np.where(todo.any(1), np.argmax(todo, axis=1), nb)
+        self.cur[switch] = nxt[switch]
+        act = self.cur < nb
+        k = np.minimum(self.cur, nb - 1)
+        pa = np.zeros((n, 3), np.float32)
+        fin = self.push.push_step(act, tip, blocks[rows, k], targets[rows, k], pa)
+        a[act] = pa[act]
+        self.push.phase[fin] = 0
+        a[~act] = 0.0
+
+
 def make_policy(task, n, **kw):
     if task == 'slide':      # the puck (radius 0.03, kuka_single_step_envs.py:49-59) needs a longer stand-off than the cube
         kw.setdefault('standoff', 0.06)
     return {'reach': ReachPolicy, 'push': PushPolicy, 'pick_and_place': PickAndPlacePolicy, 'slide': PushPolicy,
-            'block_stack': StackPolicy, 'chest_push': ChestPushPolicy,
+            'block_stack': StackPolicy, 'block_rearrange': RearrangePolicy, 'chest_push': ChestPushPolicy,
             'chest_pick_and_place': ChestPickAndPlacePolicy}[task](n, **kw)
 
 

@@ -24,6 +24,7 @@ SUITE = {
     'slide': ({}, 60),
     'block_stack_2': ({'num_block': 2}, 130),
     'block_stack_4': ({'num_block': 4}, 340),
+    'block_rearrange_2': ({'num_block': 2}, 400),
     'chest_push': ({'num_block': 1}, 360),
     'chest_pick_and_place': ({'num_block': 1}, 100),
 }
@@ -38,11 +39,13 @@ def feasible_mask(task, obs0):
         return obs0['observation'][:, 3] <= -0.45
     if task == 'chest_push':
         return obs0['observation'][:, 8] <= -0.45
+    if task == 'block_rearrange':
+        return (obs0['observation'][:, 8] <= -0.45) & (obs0['observation'][:, 24] <= -0.45)
     return np.ones(n, bool)
 
 
 def run(name, backend, N, seed=0):
-    task = name.rsplit('_', 1)[0] if name.startswith('block_stack_') else name
+    task = name.rsplit('_', 1)[0] if name.startswith(('block_stack_', 'block_rearrange_')) else name
     kw, T = SUITE[name]
     if backend == 'device':
         import pybullet_multigoal_gym_amd as pmg

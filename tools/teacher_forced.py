@@ -118,6 +118,8 @@ if __name__ == '__main__':
         import scripted_policies
         if task.startswith('chest'):
             kw['num_block'] = 1
+        if task == 'block_rearrange':
+            kw['num_block'] = 2
         kw['max_episode_steps'] = T
         pol = scripted_policies.make_policy(task, N, **({'num_block': kw['num_block']} if 'num_block' in kw else {}))
     r = run(task, N, T, kw, device=dev, policy=pol, keep_schedule=dev)
