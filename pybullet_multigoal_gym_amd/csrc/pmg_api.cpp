@@ -344,7 +344,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     CREATE_TRY(hipMalloc((void**)&e->P.blocks, N * pmg::BLOCK_DIM * (nb ? nb : 1) * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->P.rng, N * 625 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&e->P.out, N * dims.packed_dim * sizeof(float)));
-    CREATE_TRY(hipMalloc((void**)&e->P.sched, (3 + 3 * N + 3 * ((N + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS)) * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&e->P.sched, (4 + 3 * N + 3 * ((N + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS)) * sizeof(int)));
     if (const char* pk = getenv("PMG_PACKED")) e->packed = atoi(pk) != 0;
     if (const char* tw = getenv("PMG_REACH_TWO_WAVES")) e->two_wave = atoi(tw) != 0;
     {   /* 1.5 wavefronts per SIMD of this device: how many one-env wavefronts the plan may add to a step */
@@ -359,6 +359,11 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         e->P.chest_reach = 0.02f;
         if (const char* nr = getenv("PMG_NEAR_R")) e->P.near_r = (float)atof(nr);   /* (tuning experiments) */
         if (const char* cr = getenv("PMG_CHEST_REACH")) e->P.chest_reach = (float)atof(cr);
+        e->P.list0_prio = -1;
+        e->P.fd_div = PMG_FD_DIV;
+        if (const char* fd = getenv("PMG_FD_DIV")) e->P.fd_div = atoi(fd);
+        if (const char* wb = getenv("PMG_WAVE_BUDGET")) e->P.wave_budget = atoi(wb);
+        if (const char* pr = getenv("PMG_LIST0_PRIO")) e->P.list0_prio = atoi(pr);
     }
     CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
     CREATE_TRY(hipMalloc((void**)&e->d_mask, N));
@@ -377,7 +382,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         CREATE_TRY(hipMemcpy(e->P.cold, cold.data(), cold.size() * sizeof(float), hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(e->P.blocks, blk.data(), blk.size() * sizeof(float), hipMemcpyHostToDevice));
         {   /* identity launch schedule: all envs in the contact-prone list */
-            std::vector<int> sc(3 + 3 * N, 0);
+            std::vector<int> sc(4 + 3 * N + 3 * ((N + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS), 0);   /* (+ the plan's counts and its promotion flag) */
             sc[0] = (int)N;
             for (size_t i = 0; i < N; i++) sc[2 + i] = (int)i;
             CREATE_TRY(hipMemcpy(e->P.sched, sc.data(), sc.size() * sizeof(int), hipMemcpyHostToDevice));

@@ -27,6 +27,8 @@ struct EnvParams {
     float chest_reach;      /* plan: how far in front of the chest's front face a tip target counts as "at the chest" */
     float near_r;           /* plan: a tip target within this distance of a free object sends the env to the full-store list */
     int wave_budget;        /* 1.5 wavefronts per SIMD of THIS device (6 x CUs: 1536 on an MI355X): pmg_k_plan's promotion rule */
+    int fd_div;             /* plan: the fingers-down class moves to list 0 while it is under 1 / fd_div of the batch (0: never) */
+    int list0_prio;         /* s_setprio level of the full-store (list 0) wavefronts; -1: when they are the long pole of the step (pmg_k_step_list) */
     float thr;
     float ee_lo[3], ee_hi[3];
     float table_c[3], table_h[3], table_mu;
@@ -191,6 +193,12 @@ __device__ __forceinline__ int plan_class(const EnvParams& P, const float* actio
     float zn = fminf(fmaxf(z + actions[(size_t)env * P.adim + 2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
     return fminf(z, zn) < P.ee_lo[2] + 0.012f ? 1 : 2;
 }
+/* one word behind the per-workgroup counts of the two-pass plan: did the plan move the fingers-down class to list 0?
+ * (then list 0 carries the long pole of the step and its wavefronts take issue priority, pmg_k_step_list) */
+__device__ __forceinline__ int* plan_promoted(const EnvParams& P)
+{
+    return P.sched + 3 + 3 * (size_t)P.n_envs + 3 * (size_t)((P.n_envs + 1023) / 1024);
+}
 __device__ __forceinline__ void plan_all(const EnvParams& P, const float* actions)
 {
     __shared__ int cnt0[PLAN_MAX_TILES], cnt1[PLAN_MAX_TILES], cnt2[PLAN_MAX_TILES];
@@ -215,7 +223,7 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
      * any time: -24 %), so the whole class moves to the first list, behind class 0, when it is under 1 / PMG_FD_DIV of
      * the batch AND the step then still fits 1.5 wavefronts per SIMD (1024 SIMDs; at 8192 envs the packed wavefronts
      * alone are two per SIMD and the extra one-env wavefronts cost more than they save: 1.74 -> 1.65 M) */
-    const bool promote = PMG_FD_DIV > 0 && P.nb == 1 && !P.joint_control && n1 * PMG_FD_DIV <= P.n_envs &&
+    const bool promote = P.fd_div > 0 && P.nb == 1 && !P.joint_control && (long long)n1 * P.fd_div <= P.n_envs &&
                          n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget;
     for (int c = 0; c < chunks; c++) {
         int tile = c * waves + wave;
@@ -235,6 +243,7 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
         P.sched[0] = promote ? n0 + n1 : n0;
         P.sched[1] = promote ? n2 : n1 + n2;
         P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
+        *plan_promoted(P) = promote ? 1 : 0;
     }
 }
 /* Batches beyond one plan workgroup (65 536 envs): the same stable three-way partition in two passes over
@@ -281,7 +290,7 @@ __device__ __forceinline__ void plan_scatter(const EnvParams& P, const float* ac
     if (lane == 0) { wcnt[0][wave] = __popcll(m0); wcnt[1][wave] = __popcll(m1); wcnt[2][wave] = __popcll(m2); }
     __syncthreads();
     const int n0all = tot[0], n1 = tot[1], n2all = tot[2];
-    const bool promote = PMG_FD_DIV > 0 && P.nb == 1 && !P.joint_control && (long long)n1 * PMG_FD_DIV <= P.n_envs &&
+    const bool promote = P.fd_div > 0 && P.nb == 1 && !P.joint_control && (long long)n1 * P.fd_div <= P.n_envs &&
                          n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget;
     int b0 = base[0], b1 = base[1], b2 = base[2];
     for (int w = 0; w < wave && w < waves; w++) { b0 += wcnt[0][w]; b1 += wcnt[1][w]; b2 += wcnt[2][w]; }
@@ -293,6 +302,7 @@ __device__ __forceinline__ void plan_scatter(const EnvParams& P, const float* ac
         P.sched[0] = promote ? n0all + n1 : n0all;
         P.sched[1] = promote ? n2all : n1 + n2all;
         P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
+        *plan_promoted(P) = promote ? 1 : 0;
     }
 }
 __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)

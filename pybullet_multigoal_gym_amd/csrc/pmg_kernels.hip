@@ -236,6 +236,11 @@ __global__ void __launch_bounds__(LIST == 0 && PMG_LIST_TWO_WAVES ? 128 : 64, PM
     __shared__ pmg::LaneTabStore lcs;
     const int b = (int)blockIdx.x;
     if (b >= P.sched[LIST]) return;
+    /* issue priority for the wavefronts that are the long pole of the step: list 0 of the multi-block / chest tasks
+     * (block_stack-4 +2.6 %), list 0 of a one-object task when the plan moved the fingers-down class there
+     * (pick_and_place 1.59 -> 1.85 M; push / slide, whose long pole is the packed fingers-down wavefront, lose 3 / 8 %
+     * with it and do not promote); PMG_LIST0_PRIO overrides (tools/prio_exp.sh) */
+    if (LIST == 0) wv::set_priority(P.list0_prio >= 0 ? P.list0_prio : ((NB > 1 || *pmg::plan_promoted(P)) ? 1 : 0));
     const int env = P.sched[2 + LIST * P.n_envs + b];
     const bool ok = pmg::step_env_core<NB, MAXC, CYL, LIST == 0 && PMG_LIST_TWO_WAVES>(P, actions, env, L, lcs, true);
     if (!ok && threadIdx.x == 0) {

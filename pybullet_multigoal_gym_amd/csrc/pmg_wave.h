@@ -25,6 +25,13 @@ __device__ __forceinline__ void store(unsigned int v, unsigned int* p) { __built
 }  // namespace nt
 
 namespace wv {
+/* issue priority of this wavefront among the wavefronts of its SIMD (s_setprio takes an immediate) */
+__device__ __forceinline__ void set_priority(int level)
+{
+    if (level == 1) __builtin_amdgcn_s_setprio(1);
+    else if (level == 2) __builtin_amdgcn_s_setprio(2);
+    else if (level >= 3) __builtin_amdgcn_s_setprio(3);
+}
 
 constexpr int LANES = 64; /* lanes that cooperate on one env */
 __device__ __forceinline__ int lane() { return (int)threadIdx.x & 63; }   /* (two-wave workgroups: the helper wavefront's lanes) */

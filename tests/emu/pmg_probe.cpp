@@ -73,13 +73,13 @@ extern "C" int pmge_probe_plan(int n_envs, int nb, const float* hot, const float
     using namespace pmg;
     EnvParams P;
     memset(&P, 0, sizeof(P));
-    P.n_envs = n_envs; P.nb = nb; P.adim = adim; P.chest = -1; P.wave_budget = wave_budget; P.has_obj = nb > 0; P.near_r = 0.065f;
+    P.n_envs = n_envs; P.nb = nb; P.adim = adim; P.chest = -1; P.wave_budget = wave_budget; P.has_obj = nb > 0; P.near_r = 0.065f; P.fd_div = PMG_FD_DIV;
     const float lo[3] = {-0.67f, -0.2f, 0.175f}, hi[3] = {-0.37f, 0.2f, 0.55f};
     for (int a = 0; a < 3; a++) { P.ee_lo[a] = lo[a]; P.ee_hi[a] = hi[a]; }
     P.hot = const_cast<float*>(hot);
     P.blocks = const_cast<float*>(blocks);
     const int nwg = (n_envs + PLAN_THREADS - 1) / PLAN_THREADS;
-    std::vector<int> sc(3 + 3 * (size_t)n_envs + 3 * (size_t)nwg, -1);
+    std::vector<int> sc(4 + 3 * (size_t)n_envs + 3 * (size_t)nwg, -1);
     P.sched = sc.data();
     if (!two_pass) {
         if (n_envs > PLAN_MAX_TILES * 64) return -1;   /* (the launcher switches to two passes at PLAN_SINGLE_MAX already) */

@@ -24,6 +24,7 @@ constexpr int LANES = 64;
 inline int lane() { return (int)threadIdx.x & 63; }
 inline float* xbuf() { return emu_xf + ((int)threadIdx.x >> 6) * (64 * 16); } /* per-wave exchange area */
 inline void lds_sync() { emu_barrier(); }
+inline void set_priority(int) {}
 
 template <int N>
 inline void exchange_put(const float* v)
