@@ -203,11 +203,20 @@ hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipS
  * whose gripper works on the object run one per wavefront with the full 24-contact store in a SEPARATE launch
  * (pmg_k_step_list<1,24,0,CYL>, 16 KB) on the side stream, so that a batch in which most envs are of that kind keeps
  * the occupancy it had before the packing; surplus workgroups at the end of either grid exit at once */
+/* A helper wavefront for the packed kernel, too (PMG_OBJ4_TWO_WAVES=1: the narrowphase of the four envs beside their
+ * dynamics), measured SLOWER: push 1.39 -> 1.10 M, slide 1.23 -> 0.95 M, pick_and_place 1.86 -> 1.25 M.  The 1024 packed
+ * wavefronts of a 4096-env step sit one per SIMD; a second wavefront on every SIMD costs these kernels more than the
+ * 5.6 k cycles per substep it takes off the chain (placement is even -- tools/probe_placement2.hip: two waves on each of
+ * the 1024 SIMDs, never both of a workgroup on one -- and 40 KB of LDS per workgroup to force four per CU changes nothing) */
+#ifndef PMG_OBJ4_TWO_WAVES
+#define PMG_OBJ4_TWO_WAVES 0
+#endif
+constexpr int OBJ4_THREADS = PMG_OBJ4_TWO_WAVES ? 128 : 64;
 template <bool CYL>
-__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_obj4(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(OBJ4_THREADS, PMG_WAVES_PER_EU) pmg_k_step_obj4(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmgp::ObjLds4 sm;
-    pmgp::step_group_obj<CYL>(P, actions, (int)blockIdx.x, sm);
+    pmgp::step_group_obj<CYL, PMG_OBJ4_TWO_WAVES != 0>(P, actions, (int)blockIdx.x, sm);
 }
 template <bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvParams P, const float* __restrict__ actions)
@@ -306,13 +315,13 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         if (P.task == PMG_TASK_SLIDE) {
             hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
             (void)hipEventRecord(ev_join, side);
-            hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(64), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(OBJ4_THREADS), 0, s, P, d_actions);
             (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         } else {
             hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
             (void)hipEventRecord(ev_join, side);
-            hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(64), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(OBJ4_THREADS), 0, s, P, d_actions);
             (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL((pmg_k_redo_obj<false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         }

@@ -181,7 +181,8 @@ struct ObjLds4 { /* LDS of a packed workgroup: four contact stores + the lane-co
     ContactLds<1, PACKED_MAXC> Ls[4];
     LaneTabStore lcs;
 };
-template <bool CYL>
+/* TWO: 128-thread workgroups -- wavefront 1 runs the narrowphase of the four envs beside wavefront 0's dynamics (helper_wave_loop) */
+template <bool CYL, bool TWO = false>
 __device__ __forceinline__ void step_group_obj(const EnvParams& P, const float* actions, int group, ObjLds4& sm)
 {
     ContactLds<1, PACKED_MAXC>* Ls = sm.Ls;
@@ -191,7 +192,7 @@ __device__ __forceinline__ void step_group_obj(const EnvParams& P, const float* 
     const int idx = 4 * group + wr::row();
     const bool have = idx < n1;                        /* surplus rows shadow the last env and write nothing */
     const int env = P.sched[2 + P.n_envs + (have ? idx : n1 - 1)];
-    const bool ok = step_env_core<1, PACKED_MAXC, CYL>(P, actions, env, Ls[wr::row()], lcs, have);
+    const bool ok = step_env_core<1, PACKED_MAXC, CYL, TWO>(P, actions, env, Ls[wr::row()], lcs, have);
     if (have && !ok && wr::lane() == 0) {
         int* redo = P.sched + 2 + 2 * P.n_envs;
         int slot = atomicAdd(redo, 1);
