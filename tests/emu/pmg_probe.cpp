@@ -66,7 +66,7 @@ extern "C" int pmge_probe_narrowphase(int kind, const float* ca, const float* Ra
 }
 
 /* the launch-order plan in isolation: the single-workgroup plan (two_pass = 0) or the two-pass multi-workgroup plan on
- * the same batch; sched_out = [3 + 3 N] as on the device.  hot: [N, 32] state rows, blocks: [N, 13 nb], actions [N, adim] */
+ * the same batch; sched_out = [3 + 3 N] as on the device; returns the plan's promotion flag (< 0: not run).  hot: [N, 32] state rows, blocks: [N, 13 nb], actions [N, adim] */
 extern "C" int pmge_probe_plan(int n_envs, int nb, const float* hot, const float* blocks, const float* actions, int adim,
                                int wave_budget, int two_pass, int* sched_out)
 {
@@ -89,5 +89,5 @@ extern "C" int pmge_probe_plan(int n_envs, int nb, const float* hot, const float
         emu::launch(nwg, PLAN_THREADS, [&]() { plan_scatter(P, actions); });
     }
     memcpy(sched_out, sc.data(), sizeof(int) * (3 + 3 * (size_t)n_envs));
-    return 0;
+    return *plan_promoted(P);                          /* 0 / 1: the word pmg_k_step_list reads for its issue priority */
 }

@@ -411,15 +411,19 @@ def test_two_pass_plan_writes_the_same_lists_as_the_single_workgroup_plan(built,
     near = rs.uniform(0, 1, N) < 0.1                       # some grippers right at their object: class 0
     hot[near, 18:21] = blocks[near, 0:3] + np.float32([0.0, 0.0, 0.02])
     actions = rs.uniform(-1, 1, (N, adim)).astype(np.float32)
-    out = []
+    out, flags = [], []
     for two_pass in (0, 1):
         sc = np.full(3 + 3 * N, -7, np.int32)
         rc = lib.pmge_probe_plan(C.c_int(N), C.c_int(nb), hot.ctypes.data_as(C.c_void_p), blocks.ctypes.data_as(C.c_void_p),
                                  actions.ctypes.data_as(C.c_void_p), C.c_int(adim), C.c_int(1536), C.c_int(two_pass),
                                  sc.ctypes.data_as(C.c_void_p))
-        assert rc == 0
+        assert rc in (0, 1)
         out.append(sc)
+        flags.append(rc)
     a, b = out
+    # the promotion flag (list 0 takes issue priority when the fingers-down class was moved there): same in both plans,
+    # set exactly for one object with few envs down at the table
+    assert flags[0] == flags[1] == (1 if (nb == 1 and frac_down < 0.125) else 0)
     n0, n1 = int(a[0]), int(a[1])
     assert n0 + n1 == N and (n0, n1) == (int(b[0]), int(b[1])) and 0 < n0 < N
     assert np.array_equal(a[2:2 + n0], b[2:2 + n0]) and np.array_equal(a[2 + N:2 + N + n1], b[2 + N:2 + N + n1])
