@@ -48,7 +48,7 @@ for task, kw, n in (('reach', {}, 2), ('push', {}, 1), ('slide', {}, 1), ('block
 def test_product_sources_are_clean_under_ubsan_on_the_emulator(tmp_path):
     emu, src = os.path.join(ROOT, 'tests', 'emu'), os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc')
     lib = str(tmp_path / 'libpmg_emu_ubsan.so')
-    subprocess.check_call(['g++', '-O1', '-g', '-fPIC', '-std=c++17', '-I' + emu, '-I' + src, '-Wno-unknown-pragmas', '-w',
+    subprocess.check_call(['g++', '-O1', '-fPIC', '-std=c++17', '-I' + emu, '-I' + src, '-Wno-unknown-pragmas', '-w',
                            '-fsanitize=undefined', '-fno-sanitize-recover=all', '-shared', '-o', lib,
                            os.path.join(emu, 'hip_emu.cpp'), os.path.join(emu, 'pmg_probe.cpp'), os.path.join(src, 'pmg_api.cpp'),
                            '-x', 'c++', os.path.join(src, 'pmg_kernels.hip'), '-lrt'])
