@@ -73,17 +73,6 @@ def test_spaces_and_bullet_call_counts(built, emu_library, path):
     assert fx['bullet_calls']['calculateInverseKinematics'] >= 2               # constructor: robot.reset() + env.reset()
 
 
-EMULATED = ['reach_short', 'block_stack4_curriculum']
-
-
-@pytest.mark.parametrize('name', EMULATED)
-def test_emulated_kernels_reproduce_reference_session(built, emu_library, name):
-    fx = R.load(os.path.join(ROOT, 'tests', 'golden', 'ref_%s.json' % name))
-    env = R.ProductAdapter(fx, library=emu_library)
-    R.replay(fx, env, tol_static=2e-5, tol_traj=5e-4, tol_vel=5e-3, threshold_guard=1e-3)
-    env.close()
-
-
 # float32 device vs the float64 physics under the fixtures, over WHOLE episodes: resets / goals / curricula / sub-goals to
 # 2e-5 (positions of a reset are IK solutions); trajectories at BASELINE.json's 1e-3 (reach: 2e-5) -- unless the float32
 # build of the ORACLE itself, replaying the same session, strays further from the float64 fixture than 3e-4: that session
@@ -101,9 +90,7 @@ def _float32_floor(fx):
         env.close()
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize('path', PATHS, ids=NAMES)
-def test_hip_reproduces_reference_session(built, hip_library, path):
+def _replay_whole_episodes(path, library):
     fx = R.load(path)
     bars = dict(GPU_BARS.get(fx['task'], GPU_DEFAULT))
     floor = _float32_floor(fx)
@@ -112,10 +99,22 @@ def test_hip_reproduces_reference_session(built, hip_library, path):
         bars['tol_traj'] = max(bars['tol_traj'], 2 * floor['traj'])
         bars['tol_vel'] = max(bars['tol_vel'], 2 * floor['obs'])
         guard = max(guard, 2 * floor['traj'])
-    env = R.ProductAdapter(fx, library=hip_library)
+    env = R.ProductAdapter(fx, library=library)
     worst = R.replay(fx, env, tol_static=2e-5, threshold_guard=guard, traj_steps=None, **bars)
     env.close()
     print('worst', os.path.basename(path), worst, 'float32 oracle floor', floor, 'bars', bars)
+
+
+@pytest.mark.parametrize('path', PATHS, ids=NAMES)
+def test_emulated_kernels_reproduce_reference_session(built, emu_library, path):
+    """The product's kernel sources on the CPU emulator: every reference session, whole episodes, at the device's bars."""
+    _replay_whole_episodes(path, emu_library)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', PATHS, ids=NAMES)
+def test_hip_reproduces_reference_session(built, hip_library, path):
+    _replay_whole_episodes(path, hip_library)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
