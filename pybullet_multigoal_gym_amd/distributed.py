@@ -180,8 +180,10 @@ class Rendezvous:
     the list back" -- the ranks call them in the same order, so no threads and no tags are needed.  Control plane only:
     the data path of the job is the RCCL all-gather inside the library."""
 
-    def __init__(self, rank, world_size, addr=None, port=None, timeout=180.0):
+    def __init__(self, rank, world_size, addr=None, port=None, timeout=None):
         self.rank, self.world = int(rank), int(world_size)
+        if timeout is None:      # generous: on a fresh box the ranks' first import of the GPU libraries can take minutes
+            timeout = float(os.environ.get('PMG_RDV_TIMEOUT', '600'))
         addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
         if port is None:
             port = int(os.environ['PMG_RDV_PORT']) if 'PMG_RDV_PORT' in os.environ else int(os.environ.get('MASTER_PORT', '29400')) + RDV_PORT_OFFSET
