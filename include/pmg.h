@@ -57,8 +57,11 @@ enum {
     PMG_BUF_PACKED = 7,  /* [N, packed_dim] float32 rows: observation | policy_state | achieved_goal |
                             desired_goal | reward | goal_achieved (0/1) | done (0/1); widths in pmg_dims */
     PMG_BUF_STATE = 8,   /* [N, 32] float32 hot state rows (q9 qd9 ee3 jt7 grip elapsed enabled resets) */
-    PMG_BUF_SCHED = 9    /* [3 + 3N] int32 launch schedule of the last step (diagnostics): n_prone, n_free, prone list [N],
+    PMG_BUF_SCHED = 9,   /* [3 + 3N] int32 launch schedule of the last step (diagnostics): n_prone, n_free, prone list [N],
                             free list [N], n_redo, redo list [N] -- see DESIGN.md "launch-order plan" */
+    PMG_BUF_ENV_CYCLES = 10 /* [N, 2] int32 (diagnostics; only when the handle was created with PMG_ENV_CYCLES=1 in the
+                            environment, PMG_E_INVALID otherwise): shader cycles / 64 the env's wavefront spent in its last
+                            step, and the largest contact count any of that step's substeps saw (envs with free objects) */
 };
 
 /* POD configuration; mirrors the kwargs of pmg.make_env (P/__init__.py:4-11)

@@ -16,6 +16,7 @@ TASK_IDS = {'reach': 0, 'push': 1, 'pick_and_place': 2, 'slide': 3, 'block_stack
 PMG_BUF_PACKED = 7
 PMG_BUF_STATE = 8
 PMG_BUF_SCHED = 9
+PMG_BUF_ENV_CYCLES = 10
 
 
 class PmgConfig(C.Structure):
@@ -211,6 +212,14 @@ class PmgHandle:
         self.download(buf, self.device_ptr(PMG_BUF_SCHED))
         return {'prone': buf[2:2 + buf[0]].copy(), 'free': buf[2 + n:2 + n + buf[1]].copy(),
                 'redo': buf[3 + 2 * n:3 + 2 * n + buf[2 + 2 * n]].copy()}
+
+    def env_cycles(self):
+        """Per-env cost of the last step (diagnostics; the handle must have been created with PMG_ENV_CYCLES=1 in the
+        environment): [N, 2] int32 = shader cycles / 64 of the env's wavefront, largest contact count of a substep."""
+        buf = np.empty((self.N, 2), np.int32)
+        self.sync()
+        self.download(buf, self.device_ptr(PMG_BUF_ENV_CYCLES))
+        return buf
 
     def stream(self):
         p = C.c_void_p()

@@ -363,6 +363,13 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         e->P.fd_div = PMG_FD_DIV;
         if (const char* fd = getenv("PMG_FD_DIV")) e->P.fd_div = atoi(fd);
         if (const char* wb = getenv("PMG_WAVE_BUDGET")) e->P.wave_budget = atoi(wb);
+        e->P.env_cycles = nullptr;
+        if (const char* ec = getenv("PMG_ENV_CYCLES")) {
+            if (atoi(ec) != 0) {
+                CREATE_TRY(hipMalloc((void**)&e->P.env_cycles, 2 * N * sizeof(int)));
+                CREATE_TRY(hipMemset(e->P.env_cycles, 0, 2 * N * sizeof(int)));
+            }
+        }
         if (const char* pr = getenv("PMG_LIST0_PRIO")) e->P.list0_prio = atoi(pr);
     }
     CREATE_TRY(hipMalloc((void**)&e->d_actions, N * dims.action_dim * sizeof(float)));
@@ -408,7 +415,7 @@ void pmg_destroy(pmg_env* e)
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
-    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out); (void)hipFree(e->P.sched);
+    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out); (void)hipFree(e->P.sched); if (e->P.env_cycles) (void)hipFree(e->P.env_cycles);
     (void)hipFree(e->d_actions); (void)hipFree(e->d_mask);
     (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
     if (e->h_packed) (void)hipHostFree(e->h_packed);
@@ -518,6 +525,9 @@ int pmg_device_ptr(pmg_env* e, int which, void** d_ptr)
     case PMG_BUF_PACKED: *d_ptr = e->P.out; return PMG_OK;
     case PMG_BUF_STATE: *d_ptr = e->P.hot; return PMG_OK;
     case PMG_BUF_SCHED: *d_ptr = e->P.sched; return PMG_OK;
+    case PMG_BUF_ENV_CYCLES:
+        if (!e->P.env_cycles) return fail(e, PMG_E_INVALID, "pmg_device_ptr: PMG_BUF_ENV_CYCLES needs PMG_ENV_CYCLES=1 in the environment at pmg_create");
+        *d_ptr = e->P.env_cycles; return PMG_OK;
     default: return fail(e, PMG_E_INVALID, "pmg_device_ptr: buffer %d is not a device buffer (use PMG_BUF_PACKED + pmg_dims offsets)", which);
     }
 }

@@ -45,6 +45,8 @@ struct EnvParams {
     int* sched;      /* [3 + 3N]: counts of {contact-prone, other} envs, the two env lists, then the redo count + list
                         of the row-packed path (pmg_packed.h); behind it [3 x ceil(N / 1024)] per-workgroup class counts
                         of the two-pass plan (batches beyond one plan workgroup) */
+    int* env_cycles; /* diagnostics (NULL unless PMG_ENV_CYCLES=1 at creation): [N, 2] shader cycles / 64 the env's wavefront spent
+                        in its last step, and the largest contact count any of its substeps saw */
 #ifdef PMG_PROFILE
     long long* prof; /* [32] per-phase shader cycles of env 0 */
 #endif

@@ -25,6 +25,17 @@ __device__ __forceinline__ void store(unsigned int v, unsigned int* p) { __built
 }  // namespace nt
 
 namespace wv {
+/* a pointer KNOWN to point into LDS: with the assumption the compiler's address-space inference turns every access
+ * through it into ds_read / ds_write (an out-of-line function's pointer parameters are generic otherwise: flat_load) */
+template <class T>
+__device__ __forceinline__ T* as_lds(T* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)      /* (the builtin exists in the device pass only) */
+    __builtin_assume(__builtin_amdgcn_is_shared((const void*)p));
+#endif
+    return p;
+}
+__device__ __forceinline__ long long cycles() { return (long long)__builtin_readcyclecounter(); }   /* shader clock (s_memtime) */
 /* issue priority of this wavefront among the wavefronts of its SIMD (s_setprio takes an immediate) */
 __device__ __forceinline__ void set_priority(int level)
 {
@@ -231,7 +242,9 @@ namespace wr {
 
 constexpr int LANES = 16; /* lanes that cooperate on one env */
 __device__ __forceinline__ int lane() { return (int)threadIdx.x & 15; }
-__device__ __forceinline__ int row() { return ((int)threadIdx.x >> 4) & 3; }   /* (& 3: the second wavefront of a two-wave workgroup) */
+__device__ __forceinline__ int row() { return ((int)threadIdx.x >> 4) & 3; }
+template <class T>
+__device__ __forceinline__ T* as_lds(T* p) { return wv::as_lds(p); }   /* (& 3: the second wavefront of a two-wave workgroup) */
 __device__ __forceinline__ void lds_sync() { wv::lds_sync(); }
 
 /* lane SRC (compile time) of the caller's row in every lane of the row: ONE DPP move (row_newbcast, gfx90a+), which the

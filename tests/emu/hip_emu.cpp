@@ -5,6 +5,8 @@
 
 emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 float emu_xf[16 * 64 * 16];
+long long pmge_face_clip_calls = 0;
+extern "C" long long pmge_face_clip_count() { return pmge_face_clip_calls; }
 
 /* Context switch.  glibc's swapcontext() saves and restores the signal mask with two system calls per switch, and the
  * emulator switches at every cross-lane primitive of every lane; on x86-64 the fibers switch with a dozen instructions

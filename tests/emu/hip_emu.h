@@ -46,6 +46,7 @@ void emu_block_barrier();   /* workgroup-level: every live thread arrives */
 
 /* exchange buffer for cross-lane primitives */
 extern float emu_xf[16 * 64 * 16]; /* [wave][slot][lane] */
+extern long long pmge_face_clip_calls;   /* calls of box_face_clip (pmg_contact_body.inc) since load */
 
 namespace emu {
 void launch(int grid, int block, const std::function<void()>& body);

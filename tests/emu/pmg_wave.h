@@ -25,6 +25,9 @@ inline int lane() { return (int)threadIdx.x & 63; }
 inline float* xbuf() { return emu_xf + ((int)threadIdx.x >> 6) * (64 * 16); } /* per-wave exchange area */
 inline void lds_sync() { emu_barrier(); }
 inline void set_priority(int) {}
+template <class T>
+inline T* as_lds(T* p) { return p; }
+inline long long cycles() { static long long t = 0; return t += 64; }   /* (a counter: the diagnostics path stays deterministic) */
 
 template <int N>
 inline void exchange_put(const float* v)
@@ -181,6 +184,8 @@ namespace wr {
 constexpr int LANES = 16;
 inline int lane() { return (int)threadIdx.x & 15; }
 inline int row() { return ((int)threadIdx.x & 63) >> 4; }
+template <class T>
+inline T* as_lds(T* p) { return p; }
 inline int base() { return (int)threadIdx.x & 48; }
 inline void lds_sync() { emu_barrier(); }
 template <int N>

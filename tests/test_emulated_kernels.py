@@ -393,6 +393,49 @@ def test_device_narrowphase_matches_oracle_on_random_pairs(emu_library, kind):
     assert checked > 80
 
 
+def test_face_clip_is_bit_identical_to_the_general_box_box_routine(emu_library):
+    """box_box_fast serves a face contact whose incident face is NOT inside the reference face (a finger on a cube, cubes
+    stacked off-centre) with box_face_clip: clip passes over all vertices at once, batched LDS traffic.  It must return
+    exactly what the general routine (box_box: vertex-by-vertex Sutherland-Hodgman through the workspace) returns -- same
+    points, same order, same bits -- on fingers against cubes, cubes on cubes and cubes on a table-sized box, in random
+    orientations, touching, deeper and with more than four clipped vertices inside the margin."""
+    lib = C.CDLL(emu_library.path)
+    lib.pmge_probe_narrowphase.restype = C.c_int
+    rs = np.random.RandomState(11)
+
+    def rot(small):
+        q = rs.normal(size=4) * ([small, small, 1.0, 1.0] if small else 1.0); q /= np.linalg.norm(q); x, y, z, w = q
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    shapes = [(np.float32([0.0125, 0.005, 0.04]), np.float32([0.015] * 3)),      # finger x cube
+              (np.float32([0.015] * 3), np.float32([0.015] * 3)),                # cube x cube
+              (np.float32([0.015] * 3), np.float32([0.5, 0.5, 0.1]))]            # cube x table-sized box
+    lib.pmge_face_clip_count.restype = C.c_longlong
+    calls0 = lib.pmge_face_clip_count()
+    clipped = many = 0
+    for trial in range(900):
+        ha, hb = shapes[trial % 3]
+        small = 0.0 if trial % 2 else rs.choice([0.003, 0.03, 0.3])               # nearly face-parallel poses clip most
+        Ra, Rb = rot(small), (np.eye(3) if trial % 5 else rot(small))
+        n_ax = Rb[:, rs.randint(3)] * rs.choice([-1, 1])
+        reach = np.abs(Ra.T @ n_ax) @ ha + np.abs(Rb.T @ n_ax) @ hb
+        lateral = rs.normal(size=3); lateral -= n_ax * (lateral @ n_ax)
+        lateral *= rs.uniform(0, 1) * float(min(hb.min(), 0.03)) / max(np.linalg.norm(lateral), 1e-9)
+        cb = rs.uniform(-0.1, 0.1, 3)
+        ca = cb + n_ax * (reach - rs.uniform(-0.001, 0.003)) + lateral
+        a32 = [np.float32(x) for x in (ca, Ra.ravel(), ha, cb, Rb.ravel(), hb)]
+        o_new, o_old = np.zeros(40, np.float32), np.zeros(40, np.float32)
+        n_new = lib.pmge_probe_narrowphase(0, *[_fp(x) for x in a32], C.c_float(0.002), _fp(o_new))
+        n_old = lib.pmge_probe_narrowphase(2, *[_fp(x) for x in a32], C.c_float(0.002), _fp(o_old))
+        assert n_new == n_old, (trial, n_new, n_old)
+        assert np.array_equal(o_new[:10 * n_new].view(np.uint32), o_old[:10 * n_old].view(np.uint32)), (trial, o_new[:10 * n_new], o_old[:10 * n_old])
+        clipped += n_new > 0
+        many += n_new == 4
+    assert clipped > 300 and many > 100, (clipped, many)
+    assert lib.pmge_face_clip_count() - calls0 > 250          # the new path is what answered
+
+
 @pytest.mark.parametrize('nb,frac_down', [(0, 0.3), (1, 0.05), (1, 0.4)])
 def test_two_pass_plan_writes_the_same_lists_as_the_single_workgroup_plan(built, nb, frac_down):
     """Batches beyond 65 536 envs are planned by ceil(N / 1024) workgroups in two passes (pmg_k_plan_count /
