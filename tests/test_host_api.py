@@ -199,6 +199,27 @@ def test_emulated_checkpoint_round_trip(emu_library, task, kw):
     _checkpoint_round_trip(emu_library, task, 2 if task == 'reach' else 1, 1, 2, **kw)
 
 
+def test_env_cycle_diagnostics_on_the_emulator(emu_library, monkeypatch):
+    """PMG_ENV_CYCLES=1 at creation: every env's wavefront records its cycles and its largest contact count per step
+    (PMG_BUF_ENV_CYCLES / h.env_cycles(), tools/env_cycles.py); without it the buffer does not exist."""
+    from pybullet_multigoal_gym_amd._lib import PmgError
+    env = pmg.make_env(task='push', num_envs=3, seed=2, _library=emu_library)
+    env.reset()
+    with pytest.raises(PmgError):
+        env.handle.env_cycles()
+    env.close()
+    monkeypatch.setenv('PMG_ENV_CYCLES', '1')
+    env = pmg.make_env(task='push', num_envs=3, seed=2, _library=emu_library)
+    env.reset()
+    a = np.zeros((3, 3), np.float32); a[:, 2] = -1.0                # down onto the table: fingers + block on the table
+    for _ in range(3):
+        env.step(a)
+    c = env.handle.env_cycles()
+    assert c.shape == (3, 2) and (c[:, 0] > 0).all()
+    assert (c[:, 1] >= 4).all() and (c[:, 1] <= 24).all()           # the block's four table contacts at least
+    env.close()
+
+
 def test_dpp_hazard_checker_recognises_the_sequences():
     import sys
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
