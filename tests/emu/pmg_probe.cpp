@@ -57,13 +57,14 @@ extern "C" int pmge_probe_ik(const float* q, const float* target, float* q_out)
 
 /* device narrowphase on one pair (plain call: these functions use no cross-lane primitive).  kind 0: box_box_fast
  * (register front end, box_face_clip for partial face overlaps, box_box_resume for edges), 1: cyl_box with A = cylinder
- * (half = r, r, hl), 2: the general box_box alone.  out: n x 10 floats */
+ * (half = r, r, hl), 2: the general box_box alone, 3: box_box_fast with B's rotation known to be the identity.  out: n x 10 floats */
 extern "C" int pmge_probe_narrowphase(int kind, const float* ca, const float* Ra, const float* ha, const float* cb, const float* Rb,
                                       const float* hb, float margin, float* out)
 {
     alignas(16) static float W[256];
     if (kind == 0) return pmg::box_box_fast(ca, Ra, ha, cb, Rb, hb, margin, out, W);
-    if (kind == 2) return pmg::box_box(ca, Ra, ha, cb, Rb, hb, margin, out, W);   /* the general routine alone (SAT + clipping through the workspace) */
+    if (kind == 2) return pmg::box_box(ca, Ra, ha, cb, Rb, hb, margin, out, W);
+    if (kind == 3) return pmg::box_box_fast<true, true>(ca, Ra, ha, cb, Rb, hb, margin, out, W);   /* the reach kernel's instantiation: Rb known to be the identity */   /* the general routine alone (SAT + clipping through the workspace) */
     return pmg::cyl_box(ca, Ra, ha[0], ha[2], cb, Rb, hb[0], hb[1], hb[2], margin, out, W);
 }
 

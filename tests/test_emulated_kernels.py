@@ -393,6 +393,34 @@ def test_device_narrowphase_matches_oracle_on_random_pairs(emu_library, kind):
     assert checked > 80
 
 
+def test_axis_aligned_partner_front_end_is_bit_identical(emu_library):
+    """The reach kernel's narrowphase instantiation knows that box B (the table) is axis-aligned and leaves the sums with
+    exact zeros out of the separating-axis front end: same contacts, same bits as the general routine on fingers in
+    random poses over, in and beside a table-sized box."""
+    lib = C.CDLL(emu_library.path)
+    lib.pmge_probe_narrowphase.restype = C.c_int
+    rs = np.random.RandomState(3)
+    ha, hb = np.float32([0.0125, 0.005, 0.04]), np.float32([0.5, 0.4, 0.1])
+    Rb = np.eye(3, dtype=np.float32)
+    hit = 0
+    for trial in range(600):
+        q = rs.normal(size=4) * ([1, 1, 1, 1] if trial % 3 == 0 else [0.02, 0.02, 1, 1]); q /= np.linalg.norm(q); x, y, z, w = q
+        Ra = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        ext = np.abs(Ra[2]) @ ha                                     # the finger's half extent along z
+        cb = np.float32([0, 0, 0])
+        ca = np.float32([rs.uniform(-0.52, 0.52), rs.uniform(-0.42, 0.42), 0.1 + ext + rs.uniform(-0.002, 0.003)])
+        a32 = [np.float32(v) for v in (ca, Ra.ravel(), ha, cb, Rb.ravel(), hb)]
+        o1, o2 = np.zeros(40, np.float32), np.zeros(40, np.float32)
+        n1 = lib.pmge_probe_narrowphase(3, *[_fp(v) for v in a32], C.c_float(0.002), _fp(o1))
+        n2 = lib.pmge_probe_narrowphase(2, *[_fp(v) for v in a32], C.c_float(0.002), _fp(o2))
+        assert n1 == n2, (trial, n1, n2)
+        assert np.array_equal(o1[:10 * n1].view(np.uint32), o2[:10 * n2].view(np.uint32)), trial
+        hit += n1 > 0
+    assert hit > 250, hit
+
+
 def test_face_clip_is_bit_identical_to_the_general_box_box_routine(emu_library):
     """box_box_fast serves a face contact whose incident face is NOT inside the reference face (a finger on a cube, cubes
     stacked off-centre) with box_face_clip: clip passes over all vertices at once, batched LDS traffic.  It must return
