@@ -11,6 +11,7 @@ typedef struct emu_stream_s* hipStream_t;
 struct emu_event_s { std::chrono::steady_clock::time_point t; };
 typedef emu_event_s* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
+struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
