@@ -573,6 +573,25 @@ def _expected_schedule(env, actions):
     return idx[prone], idx[~prone]
 
 
+def test_env_cycle_diagnostics_on_device(built, monkeypatch):
+    """PMG_ENV_CYCLES=1: per-env shader cycles and largest contact count of the last step (PMG_BUF_ENV_CYCLES).  The envs
+    whose gripper was sent down onto the table must be the expensive ones, and every push env sees its block's table
+    contacts."""
+    monkeypatch.setenv('PMG_ENV_CYCLES', '1')
+    env = pmg.make_env(task='push', num_envs=256, seed=4)
+    env.reset()
+    a = np.zeros((256, 3), np.float32)
+    a[:128, 2] = -1.0                                     # first half: down to the table; second half: up
+    a[128:, 2] = 1.0
+    for _ in range(6):
+        env.step(a)
+    c = env.handle.env_cycles().astype(np.int64)
+    env.close()
+    assert (c[:, 0] > 0).all() and (c[:, 1] >= 4).all() and (c[:, 1] <= 24).all()
+    assert np.median(c[:128, 1]) >= 8                     # fingers on the table: eight more contacts
+    assert np.median(c[:128, 0]) > 1.15 * np.median(c[128:, 0])
+
+
 @pytest.mark.parametrize('N', [4096, 16384 + 64, 65536 + 256, 131072])
 def test_plan_schedule_at_every_batch_size(built, N):
     """One plan workgroup partitions batches up to 16 384 envs; larger ones take the two-pass plan over ceil(N / 1024)
