@@ -30,8 +30,21 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParam
  * cannot unbalance the placement of the real ones, exit on their first instruction */
 /* the device-side choice between the two reach kernels: two wavefronts per workgroup as soon as the step has a
  * contact-prone env (a threshold of 1 / 64 of the batch measured worse: one env on the table already sets the step time) */
+/* Registers of the reach kernels.  Two wavefronts per SIMD share the 512-entry unified file: 256 registers each, ArchVGPRs
+ * and AccVGPRs together.  Left alone the allocator takes all 256 as ArchVGPRs and spills the rest to SCRATCH memory -- and
+ * a scratch reload inside the substep loop is a memory round trip on the one serial chain (a build with 130 spilled
+ * registers ran at 2.4 M env-steps/s against 3.8 M).  Capping the ArchVGPRs leaves the remainder of the 256 as AccVGPRs,
+ * and the allocator spills there instead (v_accvgpr_write / _read: one VALU instruction, no memory). */
+#ifndef PMG_REACH_NUM_VGPR
+#define PMG_REACH_NUM_VGPR 232
+#endif
+#if PMG_REACH_NUM_VGPR > 0 && defined(__HIP_DEVICE_COMPILE__)
+#define PMG_REACH_VGPRS __attribute__((amdgpu_num_vgpr(PMG_REACH_NUM_VGPR)))
+#else
+#define PMG_REACH_VGPRS
+#endif
 __device__ __forceinline__ bool two_wave_step(int n_prone, int n_envs) { return n_prone > 0; }
-__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_reach(pmg::EnvParams P, const float* __restrict__ actions, int defer)
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) PMG_REACH_VGPRS pmg_k_step_reach(pmg::EnvParams P, const float* __restrict__ actions, int defer)
 {
     const int b = (int)blockIdx.x, n0 = P.sched[0];
     if (defer && two_wave_step(n0, P.n_envs)) return;       /* this step belongs to the two-wavefront kernel */
@@ -51,7 +64,7 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step_reach(pmg::En
  * device-resident rollout queues its steps far ahead of the GPU).  Variants tried:
  * the idle second wavefront of the contact-free workgroups exiting at once (0.82 ms again); the two lists as two
  * launches on two streams (1.44 ms). */
-__global__ void __launch_bounds__(128, PMG_WAVES_PER_EU) pmg_k_step_reach2(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(128, PMG_WAVES_PER_EU) PMG_REACH_VGPRS pmg_k_step_reach2(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int b = (int)blockIdx.x, n0 = P.sched[0];
     if (!two_wave_step(n0, P.n_envs)) return;               /* a (nearly) contact-free step: the one-wavefront kernel's turn */
@@ -59,7 +72,7 @@ __global__ void __launch_bounds__(128, PMG_WAVES_PER_EU) pmg_k_step_reach2(pmg::
     else pmgp::step_group(P, actions, 2 * (b - n0) + ((int)threadIdx.x >> 6));
 }
 /* envs the packed path gave up on (a finger reached the table although the plan said it would not) */
-__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) PMG_REACH_VGPRS pmg_k_redo(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
     if ((int)blockIdx.x >= redo[0]) return;

@@ -45,7 +45,35 @@ __device__ __forceinline__ void set_priority(int level)
 }
 
 constexpr int LANES = 64; /* lanes that cooperate on one env */
-__device__ __forceinline__ int lane() { return (int)threadIdx.x & 63; }   /* (two-wave workgroups: the helper wavefront's lanes) */
+/* the lane id as a value the optimiser cannot trace back to threadIdx: per-lane LDS ADDRESSES derived from it are
+ * computed where they are used (one v_mad) instead of being hoisted out of the substep loop, spilled to scratch memory
+ * and reloaded -- a memory round trip in front of the LDS access -- every substep */
+__device__ __forceinline__ int lane_local()
+{
+    int l = (int)threadIdx.x & 63;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(l));
+#endif
+    return l;
+}
+/* (two-wave workgroups: the helper wavefront's lanes.)  PMG_OPAQUE_LANE: every call yields a value the optimiser cannot
+ * trace back to threadIdx -- lane masks (l == k) and per-lane LDS addresses are then re-derived where they are used (one
+ * or two VALU instructions) instead of being hoisted out of the 100-substep loop as loop invariants, kept live across
+ * it, spilled (SGPR pairs to VGPR lanes, addresses to SCRATCH) and fetched back in front of every use */
+/* Measured (round 4): VGPR spills 16 -> 0, spilled SGPRs 305 -> 124 (reach), 335 -> 181 (one object), 178 -> 116 (blocks) --
+ * and reach 3.83 -> 3.77 M, block_stack-4 0.610 -> 0.596 M, chest_push 0.406 -> 0.395 M: in the tight loops re-deriving a
+ * mask costs more issue slots than fetching a spilled SGPR pair back.  Off; lane_local() below is the targeted form. */
+#ifndef PMG_OPAQUE_LANE
+#define PMG_OPAQUE_LANE 0
+#endif
+__device__ __forceinline__ int lane()
+{
+    int l = (int)threadIdx.x & 63;
+#if PMG_OPAQUE_LANE && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(l));
+#endif
+    return l;
+}
 
 /* wave-level LDS ordering.  A workgroup is ONE wavefront and the LDS unit executes a wavefront's DS instructions in
  * program order, so a later read sees an earlier write of any lane: all that is needed is to stop the COMPILER from
@@ -230,6 +258,11 @@ __device__ __forceinline__ unsigned any_row_mask(bool p) { return (unsigned)(__b
 __device__ __forceinline__ bool uniform_positive(float v) { return __builtin_amdgcn_readfirstlane(__float_as_int(v)) > 0; }
 /* optimisation barrier on a per-lane index: everything loaded through it is re-loaded */
 __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
+/* Software pipelining by data dependence: an address offset (always 0) that the compiler must take to depend on `done`.
+ * LDS reads addressed through it cannot be issued before `done` has been computed -- the one fence the iterative-ilp
+ * machine scheduler respects (it hoists the reads of a fully unrolled loop across sched_barrier and across asm memory
+ * clobbers alike: 72 reads in flight, 110 spilled registers). */
+__device__ __forceinline__ void chain(int& off, float& done) { asm volatile("" : "+v"(off), "+v"(done)); }
 
 }  // namespace wv
 
@@ -241,7 +274,22 @@ __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
 namespace wr {
 
 constexpr int LANES = 16; /* lanes that cooperate on one env */
-__device__ __forceinline__ int lane() { return (int)threadIdx.x & 15; }
+__device__ __forceinline__ int lane_local()
+{
+    int l = (int)threadIdx.x & 15;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(l));
+#endif
+    return l;
+}
+__device__ __forceinline__ int lane()
+{
+    int l = (int)threadIdx.x & 15;
+#if PMG_OPAQUE_LANE && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(l));
+#endif
+    return l;
+}
 __device__ __forceinline__ int row() { return ((int)threadIdx.x >> 4) & 3; }
 template <class T>
 __device__ __forceinline__ T* as_lds(T* p) { return wv::as_lds(p); }   /* (& 3: the second wavefront of a two-wave workgroup) */
@@ -350,6 +398,7 @@ __device__ __forceinline__ unsigned any_row_mask(bool p)
     return (unsigned)((b | (b >> 16) | (b >> 32) | (b >> 48)) & 0xFFFFull);
 }
 __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
+__device__ __forceinline__ void chain(int& off, float& done) { wv::chain(off, done); }
 
 }  // namespace wr
 #endif

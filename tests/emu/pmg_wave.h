@@ -22,6 +22,7 @@ static inline void store(unsigned int v, unsigned int* p) { *p = v; }
 namespace wv {
 constexpr int LANES = 64;
 inline int lane() { return (int)threadIdx.x & 63; }
+inline int lane_local() { return lane(); }
 inline float* xbuf() { return emu_xf + ((int)threadIdx.x >> 6) * (64 * 16); } /* per-wave exchange area */
 inline void lds_sync() { emu_barrier(); }
 inline void set_priority(int) {}
@@ -137,6 +138,7 @@ inline float max_all(float v)
     return fmaxf(fmaxf(bcast(v, 0), bcast(v, 16)), fmaxf(bcast(v, 32), bcast(v, 48)));
 }
 inline void opaque(int& i) { (void)i; }
+inline void chain(int& off, float& done) { (void)off; (void)done; }
 inline bool uniform_positive(float v) { return bcast(v, 0) > 0.f; } /* v_readfirstlane: lane 0 decides for the wave */
 inline unsigned long long ballot(bool p)
 {
@@ -183,6 +185,7 @@ inline void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc
 namespace wr {
 constexpr int LANES = 16;
 inline int lane() { return (int)threadIdx.x & 15; }
+inline int lane_local() { return lane(); }
 inline int row() { return ((int)threadIdx.x & 63) >> 4; }
 template <class T>
 inline T* as_lds(T* p) { return p; }
@@ -232,6 +235,7 @@ inline unsigned long long ballot(bool p)
     return m;
 }
 inline void opaque(int& i) { (void)i; }
+inline void chain(int& off, float& done) { (void)off; (void)done; }
 /* the device ORs the four rows (a wave-uniform mask that only decides which rows get a -- possibly empty -- visit);
  * rows of the emulator may have diverged, so each row answers for itself: same results, fewer empty visits */
 template <int SRC8>

@@ -37,7 +37,8 @@ int main(int argc, char** argv)
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         long long pr[32]; hipMemcpy(pr, P.prof, sizeof(pr), hipMemcpyDeviceToHost);
-        printf("rowspace: build %.0f solve %.0f cycles/substep, %.2f full iterations/substep\n", pr[11]/100., pr[12]/100., pr[14]/100.);
+        printf("rowspace: build %.0f (jacobian %.0f response %.0f coefficients %.0f) solve %.0f (motor rows %.0f normals %.0f frictions %.0f) cycles/substep, %.2f full iterations/substep\n", (pr[11]+pr[22]+pr[23])/100., pr[22]/100., pr[23]/100., pr[11]/100., pr[12]/100., pr[24]/100., pr[25]/100., pr[26]/100., pr[14]/100.);
+        if (pr[31]) printf("ik: %lld iterations, cycles/iteration: fk %.0f error %.0f jjt %.0f solve %.0f\n", pr[31], (double)pr[27]/pr[31], (double)pr[28]/pr[31], (double)pr[29]/pr[31], (double)pr[30]/pr[31]);
         printf("task %d rep %d kernel %.3f ms | cycles/substep: fk %.0f detect %.0f dyn %.0f rows %.0f pgs %.0f | whole-step cycles: ik %lld loop %lld out %lld | nc %.0f con %.0f\n", task, rep, ms, pr[0]/100., pr[1]/100., pr[2]/100., pr[3]/100., pr[4]/100., pr[5], pr[6], pr[7], pr[8]/100., pr[9]/100.);
     }
     { long long ph[32]; hipMemcpy(ph, P.prof, sizeof(ph), hipMemcpyDeviceToHost); printf("phase cycles/substep (last rep): collide-narrow %.0f compact %.0f | R1 %.0f R2 %.0f R3 %.0f R4 %.0f\n", ph[16]/100., ph[17]/100., ph[18]/100., ph[19]/100., ph[20]/100., ph[21]/100.); }
