@@ -9,7 +9,8 @@ envs, random policy, state obs), actions pre-generated and resident in HBM, and 
 the packed observation shard per step.  Episodes are max_episode_steps=50 long and their phases are STAGGERED, as in an
 RL loop that resets each env when its own episode ends: env i starts at phase i mod 50 (an untimed pre-roll of one
 episode brings the batch there) and every batched step is followed by the masked reset of the 1/50 of the batch whose
-episode just ended -- inside the timed region.  Any window of K steps therefore sees every episode phase in the same
+episode just ended (pmg_reset_done_device: the device finds them by their elapsed-step counters, no host mask) -- inside
+the timed region.  Any window of K steps therefore sees every episode phase in the same
 proportion, and `value` no longer depends on where in an episode a short window falls (`--lockstep` restores the old
 all-envs-in-phase loop).  W untimed warm-up steps, then EXACTLY K timed steps between barrier + stream sync; the slowest
 rank's time counts; rank 0 prints ONE JSON line.  Secondary fields, never `value`: `full_episodes` (the same loop over
@@ -229,8 +230,10 @@ def main():
             if not stagger and (t - phase0) % T == 0:
                 h.reset_device(None)
             h.step_device(actions + t * stride)
-            if stagger:
-                h.reset_device(masks + ((t + 1) % T) * N)
+            if stagger and t < P:
+                h.reset_device(masks + ((t + 1) % T) * N)  # untimed pre-roll: the mask table sets up the staggered phases
+            elif stagger:
+                h.reset_done_device()                      # from then on the envs whose TimeLimit ran out reset themselves on the device
             if gathered is not None:
                 h.allgather_packed(gathered)
             elif host_gather:
@@ -252,6 +255,10 @@ def main():
         el = time.perf_counter() - t0
         return rdv.max(el) if multi else el
 
+    # HIP events bracket every 4th batched step (every step in short runs): each event idles the queue for ~6 us, and all
+    # steps run the same launch sequence -- staggered phases make every step statistically the same
+    timing_every = 4 if K >= 16 else 1
+    h.timing_every(timing_every)
     if stagger:
         h.reset_device(None)
     run(0, P + W)
@@ -328,11 +335,11 @@ def main():
             'config': {'workload': "task='%s', %d vectorised envs/GPU, random policy U(-1,1), state obs, %s reward, "
                                    '%d-step episodes (%s), 100 substeps/env-step'
                                    % (args.task, N, 'dense' if args.dense_reward else 'binary', T,
-                                      'phases staggered: env i at phase i mod %d, masked reset of 1/%d of the batch after every step, inside the timed region' % (T, T)
+                                      'phases staggered: env i at phase i mod %d, device-side reset (pmg_reset_done_device) of the 1/%d of the batch whose TimeLimit ran out after every step, inside the timed region' % (T, T)
                                       if stagger else 'lockstep: one reset of the whole batch every %d steps' % T),
                        'global_envs': world * N, 'parallelism': 'env-shard x%d; %s' % (world, collective),
                        'window': ('every episode phase is present in every batched step (staggered), so a %d-step window is '
-                                  'representative; %d masked resets inside it' % (K, K)) if stagger else
+                                  'representative; %d reset launches inside it' % (K, K)) if stagger else
                                  'timed steps = episode steps %d..%d of %d-step episodes%s' % (
                                      W % T, W % T + K - 1, T, '' if K >= T else
                                      ' (shorter than an episode: see full_episodes for the phase-weighted rate)')},
@@ -345,6 +352,7 @@ def main():
                                             'match': traffic_src == src_hash},
                          'kernel': 'pmg_k_step_reach2 / pmg_k_step_reach (the device picks one per step, DESIGN.md 3.1f) + pmg_k_redo' if args.task == 'reach' else 'pmg_k_step_list / pmg_k_step_obj4 family (two concurrent launches + redo)',
                          'kernel_ms': kernel_ms, 'kernel_ms_min': kmin, 'kernel_ms_max': kmax, 'launches': launches,
+                         'timed_every': timing_every,
                          'algorithmic_bytes_per_env_step': ALGO_BYTES[args.task],
                          'note': 'serial 100-substep rigid-body chain per env held in registers: HBM-light by construction '
                                  '(SURVEY.md 8d).  What binds it is the dependent-issue latency of that chain (one wavefront '

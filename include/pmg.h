@@ -139,6 +139,13 @@ int pmg_step(pmg_env* env, const float* actions, float* observation, float* poli
 /* Device-resident variants: inputs already in HBM, outputs stay in the
  * library's device buffers (pmg_device_ptr).  Stream-ordered, no host sync. */
 int pmg_reset_device(pmg_env* env, const uint8_t* d_mask);
+/* The vectorised-env policy the reference leaves to its caller (one gym env is reset by whoever reads `done`): reset, on
+ * the device and without a host mask, exactly the envs whose episode has ended -- TimeLimit: elapsed steps >=
+ * max_episode_steps (gym TimeLimit.step; reference: P/__init__.py:148-177 `max_episode_steps`).  Same state as
+ * pmg_reset_device with the mask of those envs; in the packed row the observation / goals are the new episode's first
+ * ones while reward | goal_achieved | done keep the finished step's values (the usual auto-reset convention).
+ * Idempotent: a freshly reset env has elapsed = 0. */
+int pmg_reset_done_device(pmg_env* env);
 int pmg_step_device(pmg_env* env, const float* d_actions);
 int pmg_device_ptr(pmg_env* env, int which, void** d_ptr);
 int pmg_stream(pmg_env* env, void** hip_stream);
@@ -201,6 +208,11 @@ int pmg_download(pmg_env* env, void* h_dst, const void* d_src, uint64_t bytes); 
  * handle's stream bracket every step kernel; returns average ms per launch
  * over the launches since the last pmg_timing_reset(). */
 int pmg_timing_reset(pmg_env* env);
+/* bracket only every n-th batched step with events (default 1: every step).  An event is a barrier packet with a
+ * completion signal: the kernel behind it starts ~6 us after the one in front has drained (measured, rocprofv3 kernel
+ * trace), against ~0.1 us between kernels that follow each other directly -- two events per step were 12 us of a 1.0 ms
+ * reach step.  The untimed steps run the identical launch sequence. */
+int pmg_timing_every(pmg_env* env, int n);
 int pmg_timing_read(pmg_env* env, double* avg_step_kernel_ms, int64_t* launches);
 /* the same launches: shortest / average / longest (any pointer may be NULL).  A batched step lasts as long as its slowest
  * wavefront, so the spread shows how often envs with finger x table / object contacts were in the batch. */

@@ -114,6 +114,8 @@ struct pmg_env {
     double cv_ms = 0.0, cv_max = 0.0;
     long long cv_launches = 0;
     int ev_n = 0;
+    int ev_every = 1;                 /* events around every ev_every-th batched step (pmg_timing_every) */
+    long long step_count = 0;
     double ev_ms = 0.0, ev_min = 0.0, ev_max = 0.0;
     long long ev_launches = 0;
     bool ever_reset = false;
@@ -454,21 +456,31 @@ int pmg_reset_device(pmg_env* e, const uint8_t* d_mask)
     return PMG_OK;
 }
 
+int pmg_reset_done_device(pmg_env* e)
+{
+    if (!e) return PMG_E_INVALID;
+    if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_reset_done_device: reset() must be called (for all envs) first");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, pmg_launch_reset(e->P, nullptr, e->stream, 1));
+    return PMG_OK;
+}
+
 int pmg_step_device(pmg_env* e, const float* d_actions)
 {
     if (!e || !d_actions) return PMG_E_INVALID;
     if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_step: reset() must be called (for all envs) before the first step()");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    if (e->ev_n == EVENT_POOL) drain_events(e);
-    int i = e->ev_n++;
+    const bool timed = (e->step_count++ % e->ev_every) == 0;
+    if (timed && e->ev_n == EVENT_POOL) drain_events(e);
+    int i = timed ? e->ev_n++ : 0;
     HIP_TRY(e, pmg_launch_plan(e->P, d_actions, e->stream)); /* launch-order plan (13 us), outside the step-kernel timer */
     int mode = e->packed;
     /* reach: steps that have contact-prone envs run the two-wavefront kernel while the contact-free list is at most one
      * wavefront per SIMD (pmg_kernels.hip); mode 2 launches both kernels and the DEVICE picks one by the plan's count */
     if (e->packed && e->nb == 0 && !e->cfg.joint_control && e->two_wave && e->dims.num_envs <= (e->P.wave_budget / 6) * 16) mode = 2;
-    HIP_TRY(e, hipEventRecord(e->ev_a[i], e->stream));
+    if (timed) HIP_TRY(e, hipEventRecord(e->ev_a[i], e->stream));
     HIP_TRY(e, pmg_launch_step(e->P, d_actions, e->stream, mode, e->side, e->ev_fork, e->ev_join));
-    HIP_TRY(e, hipEventRecord(e->ev_b[i], e->stream));
+    if (timed) HIP_TRY(e, hipEventRecord(e->ev_b[i], e->stream));
     return PMG_OK;
 }
 
@@ -795,11 +807,19 @@ int pmg_timing_reset(pmg_env* e)
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     e->ev_n = 0;
+    e->step_count = 0;
     e->ev_ms = e->ev_min = e->ev_max = 0.0;
     e->ev_launches = 0;
     e->cv_n = 0;
     e->cv_ms = e->cv_max = 0.0;
     e->cv_launches = 0;
+    return PMG_OK;
+}
+int pmg_timing_every(pmg_env* e, int n)
+{
+    if (!e || n < 1) return PMG_E_INVALID;
+    e->ev_every = n;
+    e->step_count = 0;
     return PMG_OK;
 }
 int pmg_timing_stats(pmg_env* e, double* min_ms, double* avg_ms, double* max_ms, int64_t* launches)

@@ -128,10 +128,25 @@ __device__ inline void plan_fk(const float* q, float& finger_z, float* tip)
     for (int a = 0; a < 3; a++) tip[a] = p6[a] + R6[3 * a + 2] * TIP_Z;
 }
 
-__device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* actions, int env)
+/* what every tip-control classification reads: the env's tip target and the first three action components.  Fetched
+ * unconditionally and up front, so that the loads of several envs of one thread are in flight together (plan_all) */
+struct PlanIn { float ee[3], a[3]; };
+template <bool Z_ONLY = false>
+__device__ __forceinline__ PlanIn plan_fetch(const EnvParams& P, const float* actions, int env)
 {
+    PlanIn in;
     const float* hot = P.hot + (size_t)env * HOT_DIM;
     const float* act = actions + (size_t)env * P.adim;
+    /* Z_ONLY (reach): two loads per env instead of six.  The plan is ONE workgroup on one compute unit and these are
+     * per-lane cache lines: 1024 threads x 4 chunks x 6 loads kept its texture-address unit busy for ~5 us (timestamps
+     * inside the kernel: fetch + first barrier 5.5 of its 8.6 us) */
+#pragma unroll
+    for (int a = Z_ONLY ? 2 : 0; a < 3; a++) { in.ee[a] = hot[18 + a]; in.a[a] = act[a]; }   /* (every task's action has >= 3 components) */
+    return in;
+}
+__device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* actions, int env, const PlanIn& in)
+{
+    const float* hot = P.hot + (size_t)env * HOT_DIM;
     if (P.joint_control) {
         /* joint targets move by up to 0.05 rad per step (kuka.py:205): with the ~0.8 m reach of the arm a finger or the
          * tip travels at most ~4.5 cm.  Prone = a finger could get inside the contact margin of the table, or the tip
@@ -153,7 +168,7 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
          * pmg_k_step_list); the count only grows past that when the fingers work on an object, i.e. when the tip
          * target comes within 6.5 cm of one */
         float t[3];
-        for (int a = 0; a < 3; a++) t[a] = fminf(fmaxf(hot[18 + a] + act[a] * 0.01f, P.ee_lo[a]), P.ee_hi[a]);
+        for (int a = 0; a < 3; a++) t[a] = fminf(fmaxf(in.ee[a] + in.a[a] * 0.01f, P.ee_lo[a]), P.ee_hi[a]);
         bool near = false;
         for (int b = 0; b < P.nb; b++) {
             const float* p = P.blocks + ((size_t)env * P.nb + b) * BLOCK_DIM;
@@ -172,8 +187,8 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
         }
         return near;
     }
-    float z = hot[20];                                    /* tip target: the tip is within mm of it */
-    float zn = fminf(fmaxf(z + act[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
+    float z = in.ee[2];                                   /* tip target: the tip is within mm of it */
+    float zn = fminf(fmaxf(z + in.a[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
     return fminf(z, zn) < P.ee_lo[2] + 0.012f;
 }
 /* one 1024-thread workgroup partitions all envs (stable, no atomics): per-wave ballots, counts of
@@ -186,14 +201,17 @@ constexpr int PLAN_SINGLE_MAX = 16384;   /* the single-workgroup plan serves bat
 /* class of an env for the launch order: 0 = first list (one env per wavefront, full contact store), 1 / 2 = second
  * list (fast path).  With free objects the fast-path envs are grouped by whether the fingers are down at the table
  * (class 1) or up (class 2): the four envs of a packed wavefront then mostly walk the same contact code paths */
+__device__ __forceinline__ int plan_class(const EnvParams& P, const float* actions, int env, const PlanIn& in)
+{
+    if (contact_prone(P, actions, env, in)) return 0;
+    if (P.nb == 0) return 1;
+    float z = in.ee[2];
+    float zn = fminf(fmaxf(z + in.a[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
+    return fminf(z, zn) < P.ee_lo[2] + 0.012f ? 1 : 2;
+}
 __device__ __forceinline__ int plan_class(const EnvParams& P, const float* actions, int env)
 {
-    if (contact_prone(P, actions, env)) return 0;
-    if (P.nb == 0) return 1;
-    const float* hot = P.hot + (size_t)env * HOT_DIM;
-    float z = hot[20];
-    float zn = fminf(fmaxf(z + actions[(size_t)env * P.adim + 2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
-    return fminf(z, zn) < P.ee_lo[2] + 0.012f ? 1 : 2;
+    return plan_class(P, actions, env, plan_fetch(P, actions, env));
 }
 /* one word behind the per-workgroup counts of the two-pass plan: did the plan move the fingers-down class to list 0?
  * (then list 0 carries the long pole of the step and its wavefronts take issue priority, pmg_k_step_list) */
@@ -201,15 +219,42 @@ __device__ __forceinline__ int* plan_promoted(const EnvParams& P)
 {
     return P.sched + 3 + 3 * (size_t)P.n_envs + 3 * (size_t)((P.n_envs + 1023) / 1024);
 }
+/* SIMPLE: reach under tip control -- the class is one compare on the tip target's height; its own instantiation keeps
+ * the general classification (joint-control FK, object and chest tests: 5 000 instructions nobody executes for reach)
+ * out of the kernel */
+template <bool SIMPLE = false>
 __device__ __forceinline__ void plan_all(const EnvParams& P, const float* actions)
 {
     __shared__ int cnt0[PLAN_MAX_TILES], cnt1[PLAN_MAX_TILES], cnt2[PLAN_MAX_TILES];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = PLAN_THREADS / 64;
     const int chunks = (P.n_envs + PLAN_THREADS - 1) / PLAN_THREADS;
     const unsigned long long below = (1ull << lane) - 1ull;
+    /* every env is classified ONCE (two bits per chunk kept in a register; the second pass used to classify again: eight
+     * rounds of dependent global loads for 4096 envs, 16 us), and the loads of four chunks are in flight together */
+    unsigned clsbits = 0;                                   /* chunks <= PLAN_SINGLE_MAX / PLAN_THREADS = 16 */
+    static_assert(PLAN_SINGLE_MAX / PLAN_THREADS <= 16, "two class bits per chunk in one register");
+    for (int c0 = 0; c0 < chunks && c0 < 16; c0 += 4) {     /* (a caller beyond PLAN_SINGLE_MAX: chunks 16.. are classified below) */
+        PlanIn in[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int env = (c0 + k) * PLAN_THREADS + tid;
+            in[k] = plan_fetch<SIMPLE>(P, actions, env < P.n_envs ? env : 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int env = (c0 + k) * PLAN_THREADS + tid;
+            int cls;
+            if (SIMPLE) {
+                const float z = in[k].ee[2], zn = fminf(fmaxf(z + in[k].a[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
+                cls = fminf(z, zn) < P.ee_lo[2] + 0.012f ? 0 : 1;        /* = plan_class for nb == 0, tip control */
+            } else cls = plan_class(P, actions, env, in[k]);
+            cls = env < P.n_envs ? cls : 3;
+            clsbits |= (unsigned)cls << (2 * (c0 + k));
+        }
+    }
     for (int c = 0; c < chunks; c++) {
-        int env = c * PLAN_THREADS + tid;
-        int cls = env < P.n_envs ? plan_class(P, actions, env) : -1;
+        const int env = c * PLAN_THREADS + tid;
+        const int cls = c < 16 ? (int)((clsbits >> (2 * c)) & 3u) : (env < P.n_envs ? plan_class(P, actions, env) : 3);
         unsigned long long m0 = wv::ballot(cls == 0), m1 = wv::ballot(cls == 1), m2 = wv::ballot(cls == 2);
         if (lane == 0 && c * waves + wave < PLAN_MAX_TILES) {
             cnt0[c * waves + wave] = __popcll(m0); cnt1[c * waves + wave] = __popcll(m1); cnt2[c * waves + wave] = __popcll(m2);
@@ -217,8 +262,24 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
     }
     __syncthreads();
     const int tiles = chunks * waves < PLAN_MAX_TILES ? chunks * waves : PLAN_MAX_TILES;
-    int n1 = 0, n0all = 0, n2all = 0;
-    for (int t = 0; t < tiles; t++) { n1 += cnt1[t]; n0all += cnt0[t]; n2all += cnt2[t]; }   /* class 2 starts behind all of class 1 in the second list */
+    /* exclusive prefix over the tiles, in place, one thread per class (eight counts per LDS round trip) -- every thread
+     * used to add up the tiles before its own, 1024 threads x up to 64 tiles x 3 classes on ONE compute unit's LDS: most
+     * of the kernel's 16 us */
+    __shared__ int tot[3];
+    if (lane == 0 && wave < 3) {
+        int* cn = wave == 0 ? cnt0 : (wave == 1 ? cnt1 : cnt2);
+        int run = 0;
+        for (int t = 0; t < tiles; t += 8) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = t + k < tiles ? cn[t + k] : 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { if (t + k < tiles) cn[t + k] = run; run += v[k]; }
+        }
+        tot[wave] = run;
+    }
+    __syncthreads();
+    const int n0all = tot[0], n1 = tot[1], n2all = tot[2];   /* class 2 starts behind all of class 1 in the second list */
     /* one free object, fingers down at the table (class 1: 8 more contacts = 24 more rows per sweep): such an env holds
      * its packed wavefront back for the whole step, alone on a wavefront it solves them in row space.  Worth a wavefront
      * each only while they are few (pick_and_place: +12 %; push / slide, where a fifth of the batch is down there at
@@ -230,18 +291,17 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
     for (int c = 0; c < chunks; c++) {
         int tile = c * waves + wave;
         int env = c * PLAN_THREADS + tid;
-        int cls = (env < P.n_envs && tile < PLAN_MAX_TILES) ? plan_class(P, actions, env) : -1;
+        int cls = (env < P.n_envs && tile < PLAN_MAX_TILES) ? (c < 16 ? (int)((clsbits >> (2 * c)) & 3u) : plan_class(P, actions, env)) : 3;
         unsigned long long m0 = wv::ballot(cls == 0), m1 = wv::ballot(cls == 1), m2 = wv::ballot(cls == 2);
-        int b0 = 0, b1 = 0, b2 = 0;
-        for (int t = 0; t < tile && t < tiles; t++) { b0 += cnt0[t]; b1 += cnt1[t]; b2 += cnt2[t]; }
+        const int tt = tile < tiles ? tile : 0;
+        const int b0 = cnt0[tt], b1 = cnt1[tt], b2 = cnt2[tt];
         if (cls == 0) P.sched[2 + b0 + __popcll(m0 & below)] = env;
         else if (cls == 1 && promote) P.sched[2 + n0all + b1 + __popcll(m1 & below)] = env;
         else if (cls == 1) P.sched[2 + P.n_envs + b1 + __popcll(m1 & below)] = env;
         else if (cls == 2) P.sched[2 + P.n_envs + (promote ? 0 : n1) + b2 + __popcll(m2 & below)] = env;
     }
     if (tid == 0) {
-        int n0 = 0, n2 = 0;
-        for (int t = 0; t < tiles; t++) { n0 += cnt0[t]; n2 += cnt2[t]; }
+        const int n0 = n0all, n2 = n2all;
         P.sched[0] = promote ? n0 + n1 : n0;
         P.sched[1] = promote ? n2 : n1 + n2;
         P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
@@ -512,17 +572,20 @@ __device__ __forceinline__ void task_reset_lane0(const EnvParams& P, int env)
 }
 
 /* env.reset(): kuka.py:120-165 + the task reset above + _get_obs */
-__device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned char* mask)
+/* done_only (pmg_reset_done_device): the envs whose episode has ended by TimeLimit reset themselves, every other workgroup
+ * leaves on its first load; the packed row keeps the finished step's reward | goal_achieved | done */
+__device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned char* mask, int done_only = 0)
 {
     __shared__ LaneTabStore lcs;
     int env = (int)blockIdx.x, l = wv::lane();
     if (env >= P.n_envs) return;
+    float* hot = P.hot + (size_t)env * HOT_DIM;
+    if (done_only && (int)hot[29] < P.max_steps) return;
     LaneConst c;
     load_lane_const(lcs, c);
-    float* hot = P.hot + (size_t)env * HOT_DIM;
     float* cold = P.cold + (size_t)env * COLD_DIM;
     int ll = l < NJ ? l : 0;
-    bool doit = mask == nullptr || mask[env] != 0;
+    bool doit = done_only || mask == nullptr || mask[env] != 0;
     float q, qd;
     int elapsed;
     if (doit) {
@@ -556,7 +619,7 @@ __device__ __forceinline__ void reset_env(const EnvParams& P, const unsigned cha
         qd = l < NJ ? hot[9 + ll] : 0.f;
         elapsed = (int)hot[29];
     }
-    write_outputs(P, env, c, q, qd, elapsed, doit ? TAIL_ZERO : TAIL_KEEP);
+    write_outputs(P, env, c, q, qd, elapsed, (doit && !done_only) ? TAIL_ZERO : TAIL_KEEP);
 }
 
 }  // namespace pmg

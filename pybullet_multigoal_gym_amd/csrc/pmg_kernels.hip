@@ -4,6 +4,7 @@
  * pmg_k_plan decides per step which envs go where (DESIGN.md sections 3.1-3.1c).
  */
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "pmg_kernels.h"
 #include "pmg_launch.h"
@@ -83,6 +84,10 @@ __global__ void __launch_bounds__(1024) pmg_k_plan(pmg::EnvParams P, const float
 {
     pmg::plan_all(P, actions);
 }
+__global__ void __launch_bounds__(1024) pmg_k_plan_reach(pmg::EnvParams P, const float* __restrict__ actions)
+{
+    pmg::plan_all<true>(P, actions);
+}
 
 __global__ void __launch_bounds__(1024) pmg_k_plan_count(pmg::EnvParams P, const float* __restrict__ actions)
 {
@@ -93,9 +98,9 @@ __global__ void __launch_bounds__(1024) pmg_k_plan_scatter(pmg::EnvParams P, con
     pmg::plan_scatter(P, actions);
 }
 
-__global__ void __launch_bounds__(64) pmg_k_reset(pmg::EnvParams P, const unsigned char* __restrict__ mask)
+__global__ void __launch_bounds__(64) pmg_k_reset(pmg::EnvParams P, const unsigned char* __restrict__ mask, int done_only)
 {
-    pmg::reset_env(P, mask);
+    pmg::reset_env(P, mask, done_only);
 }
 
 /* _compute_reward on [B, G] batches (HER relabelling): kuka_single_step_base_env.py:237-244.
@@ -204,7 +209,9 @@ hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipS
     /* one workgroup plans a batch in one launch (13 us at 4096 envs, but its 1024 threads walk the batch in chunks: 0.9 ms
      * at 65 536); beyond PLAN_SINGLE_MAX envs the two-pass plan over ceil(N / 1024) workgroups takes over: same lists
      * (tests/test_emulated_kernels.py), every batch size keeps the fast paths */
-    if (P.n_envs <= pmg::PLAN_SINGLE_MAX) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    static const int force_two_pass = getenv("PMG_PLAN_TWO_PASS") ? atoi(getenv("PMG_PLAN_TWO_PASS")) : 0;   /* (experiments) */
+    if (P.n_envs <= pmg::PLAN_SINGLE_MAX && !force_two_pass && P.nb == 0 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan_reach, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    else if (P.n_envs <= pmg::PLAN_SINGLE_MAX && !force_two_pass) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     else {
         const int nwg = (P.n_envs + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS;
         hipLaunchKernelGGL(pmg_k_plan_count, dim3(nwg), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
@@ -375,9 +382,9 @@ hipError_t pmg_launch_sub_goal(const pmg::EnvParams& P, const unsigned char* d_m
     hipLaunchKernelGGL(pmg_k_sub_goal, dim3((threads + 255) / 256), dim3(256), 0, s, P, d_mask, level);
     return hipGetLastError();
 }
-hipError_t pmg_launch_reset(const pmg::EnvParams& P, const unsigned char* d_mask, hipStream_t s)
+hipError_t pmg_launch_reset(const pmg::EnvParams& P, const unsigned char* d_mask, hipStream_t s, int done_only)
 {
-    hipLaunchKernelGGL(pmg_k_reset, dim3(P.n_envs), dim3(64), 0, s, P, d_mask);
+    hipLaunchKernelGGL(pmg_k_reset, dim3(P.n_envs), dim3(64), 0, s, P, d_mask, done_only);
     return hipGetLastError();
 }
 hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int G, float thr, int binary, float* reward,

@@ -780,3 +780,62 @@ def test_two_wavefront_reach_kernel_is_bit_identical_to_the_one_wavefront_kernel
     assert touched > N // 4                                   # the two-wave workgroups did carry those steps
     assert np.array_equal(a2.get_state(), a1.get_state())
     a2.close(), a1.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('task,kw', [('reach', {}), ('push', {}), ('block_stack', {'num_block': 3, 'use_curriculum': True, 'num_goals_to_generate': 300})])
+def test_device_side_done_reset_equals_step_plus_masked_reset(built, task, kw):
+    """pmg_reset_done_device (include/pmg.h: the envs whose TimeLimit ran out reset themselves on the device, no host mask)
+    against the same rollout with pmg_reset_device and the mask of the done envs built on the host: staggered 6-step
+    episodes over 20 steps, 256 envs.  State rows, RNG streams and the observation / goal part of the packed rows must be
+    EQUAL bit for bit after every step; reward | goal_achieved | done differ by design -- the done-reset keeps the
+    finished step's values in the row (auto-reset convention), the masked reset zeroes them -- and calling it twice is a
+    no-op."""
+    N, T = 256, 6
+    a, b = (pmg.make_env(task=task, num_envs=N, seed=31, seed_stride=1, max_episode_steps=T, **kw) for _ in range(2))
+    a.reset(), b.reset()
+    ha, hb = a.handle, b.handle
+    A = a.dims.action_dim
+    # stagger the phases: env i is reset once more after (i mod T) steps, in both envs alike
+    rs = np.random.RandomState(5)
+    acts = rs.uniform(-1, 1, (T + 20, N, A)).astype(np.float32)
+    d_act = ha.device_alloc(acts[0].nbytes)
+    d_mask = ha.device_alloc(N)
+    d_act_b = hb.device_alloc(acts[0].nbytes)
+    d_mask_b = hb.device_alloc(N)
+    packed_a = np.empty((N, a.dims.packed_dim), np.float32)
+    packed_b = np.empty_like(packed_a)
+    tail = a.dims.packed_dim - 3
+    n_resets = 0
+    for t in range(T + 20):
+        ha.upload(d_act, acts[t]); hb.upload(d_act_b, acts[t])
+        ha.step_device(d_act); hb.step_device(d_act_b)
+        hb.sync()
+        hb.download(packed_b, hb.device_ptr())
+        done = packed_b[:, tail + 2] != 0
+        if t < T:                                   # pre-roll: the host mask sets up the staggering on both sides
+            m = ((np.arange(N) + t + 1) % T == 0).astype(np.uint8)
+            ha.upload(d_mask, m); hb.upload(d_mask_b, m)
+            ha.reset_device(d_mask); hb.reset_device(d_mask_b)
+        else:
+            expected = (np.arange(N) + t + 1) % T == 0
+            assert np.array_equal(done, expected), t        # TimeLimit's done IS the staggered phase
+            n_resets += int(done.sum())
+            ha.reset_done_device()
+            ha.reset_done_device()                          # idempotent: a freshly reset env has elapsed = 0
+            hb.upload(d_mask_b, done.astype(np.uint8))
+            hb.reset_device(d_mask_b)
+        ha.sync(); hb.sync()
+        ha.download(packed_a, ha.device_ptr()); hb.download(packed_b, hb.device_ptr())
+        assert np.array_equal(packed_a[:, :tail], packed_b[:, :tail]), t
+        assert np.array_equal(a.get_state(), b.get_state()), t
+        if t >= T:
+            was = (np.arange(N) + t + 1) % T == 0
+            assert np.all(packed_a[was, tail + 2] == 1.0) and np.all(packed_b[was, tail:] == 0.0)   # kept vs zeroed tails
+            assert np.array_equal(packed_a[~was, tail:], packed_b[~was, tail:])
+    assert n_resets > 0
+    assert np.array_equal(ha.get_rng(), hb.get_rng())      # the same draws were taken from every env's stream
+    for h, ptrs in ((ha, (d_act, d_mask)), (hb, (d_act_b, d_mask_b))):
+        for p in ptrs:
+            h.device_free(p)
+    a.close(), b.close()
