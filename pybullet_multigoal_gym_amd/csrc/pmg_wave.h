@@ -258,6 +258,25 @@ __device__ __forceinline__ unsigned any_row_mask(bool p) { return (unsigned)(__b
 __device__ __forceinline__ bool uniform_positive(float v) { return __builtin_amdgcn_readfirstlane(__float_as_int(v)) > 0; }
 /* optimisation barrier on a per-lane index: everything loaded through it is re-loaded */
 __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
+/* lane LANE takes a, every other lane keeps b.  The predicate is a compile-time CONSTANT lane mask handed to v_cndmask in
+ * an SGPR pair (one or two s_mov) -- written as `l == LANE ? a : b` the compare is hoisted out of the substep loop as a
+ * loop invariant, one SGPR pair per distinct lane, and with 24 contact rows + 9 DoFs those pairs are spilled to VGPR lanes
+ * and fetched back with two v_readlane in front of every visit (ISA census of the reach kernel: 240 per contact substep) */
+/* Measured (round 4): reach 4.07 -> 3.96 M, pick_and_place 2.04 -> 2.01 M with the constant masks -- the s_mov_b64 + the wait
+ * state between an SALU write and the VALU read of the pair cost more than the two v_readlane they replace.  Off. */
+#ifndef PMG_CONST_LANE_MASKS
+#define PMG_CONST_LANE_MASKS 0
+#endif
+__device__ __forceinline__ float sel_lane(float a, float b, int l, int lane_k)   /* lane_k: a constant once the caller's loop is unrolled */
+{
+#if PMG_CONST_LANE_MASKS && defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(1ull << lane_k));
+    return r;
+#else
+    return l == lane_k ? a : b;
+#endif
+}
 /* Software pipelining by data dependence: an address offset (always 0) that the compiler must take to depend on `done`.
  * LDS reads addressed through it cannot be issued before `done` has been computed -- the one fence the iterative-ilp
  * machine scheduler respects (it hoists the reads of a fully unrolled loop across sched_barrier and across asm memory
@@ -399,6 +418,7 @@ __device__ __forceinline__ unsigned any_row_mask(bool p)
 }
 __device__ __forceinline__ void opaque(int& i) { asm volatile("" : "+v"(i)); }
 __device__ __forceinline__ void chain(int& off, float& done) { wv::chain(off, done); }
+__device__ __forceinline__ float sel_lane(float a, float b, int l, int lane_k) { return l == lane_k ? a : b; }   /* (lane_k of EACH 16-lane row) */
 
 }  // namespace wr
 #endif

@@ -139,6 +139,7 @@ inline float max_all(float v)
 }
 inline void opaque(int& i) { (void)i; }
 inline void chain(int& off, float& done) { (void)off; (void)done; }
+inline float sel_lane(float a, float b, int l, int lane_k) { return l == lane_k ? a : b; }
 inline bool uniform_positive(float v) { return bcast(v, 0) > 0.f; } /* v_readfirstlane: lane 0 decides for the wave */
 inline unsigned long long ballot(bool p)
 {
@@ -236,6 +237,7 @@ inline unsigned long long ballot(bool p)
 }
 inline void opaque(int& i) { (void)i; }
 inline void chain(int& off, float& done) { (void)off; (void)done; }
+inline float sel_lane(float a, float b, int l, int lane_k) { return l == lane_k ? a : b; }
 /* the device ORs the four rows (a wave-uniform mask that only decides which rows get a -- possibly empty -- visit);
  * rows of the emulator may have diverged, so each row answers for itself: same results, fewer empty visits */
 template <int SRC8>
