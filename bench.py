@@ -51,8 +51,7 @@ def _committed(pattern):
 
 def kernel_source_hash():
     """sha256 over the sources libpmg_hip.so is built from (csrc/*, include/*.h, the Makefile with its flags): what ties a
-    committed counter pass to the kernels that are running.  The .so itself is not hashed: hipcc stamps build metadata
-    into it, so a rebuild from the same sources differs byte-wise."""
+    committed counter pass to the kernels that are running (library_hash() ties it to the binary as well)."""
     import glob
     import hashlib
     h = hashlib.sha256()
@@ -68,6 +67,17 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def library_hash(path=None):
+    """sha256 of the libpmg_hip.so that is (or would be) loaded.  hipcc builds of the same sources are byte-identical (the
+    round-3 review rebuilt the library and compared), so this ties a counter pass to the exact binary that ran."""
+    import hashlib
+    path = path or os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc', 'libpmg_hip.so')
+    try:
+        return hashlib.sha256(open(path, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def committed_traffic(task, n_envs):
     """HBM bytes per batched step from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs of this same command, KiB -> bytes, with the calibration factors of the
@@ -77,10 +87,10 @@ def committed_traffic(task, n_envs):
         try:
             d = json.load(open(f))
             if d.get('task') == task and d.get('envs_per_gpu') == n_envs:
-                return float(d['hbm_bytes_per_launch']), d.get('kernel_source_sha16'), os.path.basename(f)
+                return float(d['hbm_bytes_per_launch']), d.get('kernel_source_sha16'), os.path.basename(f), d.get('library_sha16')
         except Exception:
             continue
-    return None, None, None
+    return None, None, None, None
 
 
 def committed_counters(task, n_envs):
@@ -190,7 +200,17 @@ def main():
     rdv = Rendezvous(rank, world) if multi else None
 
     N, K, W, T = args.envs_per_gpu, args.steps, args.warmup, args.episode_steps
-    env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=local_rank, seed=0, seed_stride=1,
+    # a launcher that restricts visibility per rank (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = one GPU each) leaves every
+    # rank with a single device 0: fall back to it instead of failing on device LOCAL_RANK
+    device = local_rank
+    try:
+        ndev = PmgLibrary(args.lib).device_count()
+        if ndev > 0 and local_rank >= ndev:
+            device = local_rank % ndev
+            print('bench.py: rank %d sees %d device(s); using device %d' % (rank, ndev, device), file=sys.stderr)
+    except Exception:
+        pass
+    env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=device, seed=0, seed_stride=1,
                        env_index_offset=rank * N, max_episode_steps=T, binary_reward=not args.dense_reward,
                        _library=PmgLibrary(args.lib) if args.lib else None)
     h = env.handle
@@ -225,6 +245,8 @@ def main():
         masks = h.device_alloc(m.nbytes)
         h.upload(masks, m)
 
+    host_gather_s = [0.0, 0]                               # FALLBACK path only: seconds in download + TCP all-gather, and how many
+
     def run(first, count, phase0=0):
         for t in range(first, first + count):
             if not stagger and (t - phase0) % T == 0:
@@ -238,8 +260,11 @@ def main():
                 h.allgather_packed(gathered)
             elif host_gather:
                 h.sync()
+                tg = time.perf_counter()
                 h.download(mine, h.device_ptr())
                 rdv.allgather(mine)
+                host_gather_s[0] += time.perf_counter() - tg
+                host_gather_s[1] += 1
 
     def fence():
         h.sync()                       # the library's stream: every kernel and the all-gather
@@ -276,21 +301,24 @@ def main():
         el_all = time.perf_counter() - t0
         return rdv.max(el_all) if multi else el_all
 
+    host_gather_s[0], host_gather_s[1] = 0.0, 0
     el = timed_keep(P + W, K)
+    hg_ms = host_gather_s[0] / max(1, host_gather_s[1]) * 1e3
     kmin, kernel_ms, kmax, launches = h.timing_stats()
     per_rank = None
     if multi:
         # diagnosability of the N > 1 run: every rank's own wall clock, step-kernel average and all-gather events
         cavg, cmax, cn = h.comm_timing() if gathered is not None else (0.0, 0.0, 0)
-        rows = rdv.allgather(np.array([el_local / K * 1e3, kernel_ms, kmax, cavg, cmax, float(cn)], np.float64))
+        rows = rdv.allgather(np.array([el_local / K * 1e3, kernel_ms, kmax, cavg, cmax, float(cn), hg_ms], np.float64))
         if rank == 0:
-            rows = np.asarray(rows).reshape(world, 6)
+            rows = np.asarray(rows).reshape(world, 7)
             per_rank = {'ms_per_step': [round(float(x), 4) for x in rows[:, 0]],
                         'kernel_ms': [round(float(x), 4) for x in rows[:, 1]],
                         'kernel_ms_max': [round(float(x), 4) for x in rows[:, 2]],
                         'allgather_ms': [round(float(x), 4) for x in rows[:, 3]],
                         'allgather_ms_max': [round(float(x), 4) for x in rows[:, 4]],
                         'allgather_launches': [int(x) for x in rows[:, 5]],
+                        'host_gather_ms': [round(float(x), 4) for x in rows[:, 6]],   # FALLBACK only: D2H + TCP all-gather per step
                         'rank_spread_ms': round(float(rows[:, 0].max() - rows[:, 0].min()), 4),
                         'slowest_rank': int(rows[:, 0].argmax()),
                         'note': 'ms_per_step: each rank\'s own clock over its K steps (value uses the slowest rank incl. the '
@@ -324,7 +352,8 @@ def main():
         algo = ALGO_BYTES[args.task] * N
         achieved = algo / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         src_hash = kernel_source_hash()
-        traffic, traffic_src, traffic_file = committed_traffic(args.task, N)
+        traffic, traffic_src, traffic_file, traffic_lib = committed_traffic(args.task, N)
+        lib_hash = library_hash(args.lib)
         cnt, cnt_src, cnt_file = committed_counters(args.task, N)
         out = {
             'metric': 'env-steps/sec at N_envs=4096/GPU, KukaReach' if args.task == 'reach' and N == 4096
@@ -349,7 +378,8 @@ def main():
                          # THESE kernel sources (sha256 of csrc/ + include/ stamped into the pass), else null
                          'traffic': traffic if (traffic_src == src_hash) else None,
                          'traffic_source': {'file': traffic_file, 'profiled_kernel_sources': traffic_src, 'running_kernel_sources': src_hash,
-                                            'match': traffic_src == src_hash},
+                                            'match': traffic_src == src_hash, 'profiled_library': traffic_lib, 'running_library': lib_hash,
+                                            'library_match': (traffic_lib == lib_hash) if traffic_lib else None},
                          'kernel': 'pmg_k_step_reach2 / pmg_k_step_reach (the device picks one per step, DESIGN.md 3.1f) + pmg_k_redo' if args.task == 'reach' else 'pmg_k_step_list / pmg_k_step_obj4 family (two concurrent launches + redo)',
                          'kernel_ms': kernel_ms, 'kernel_ms_min': kmin, 'kernel_ms_max': kmax, 'launches': launches,
                          'timed_every': timing_every,

@@ -57,8 +57,9 @@ enum {
     PMG_BUF_PACKED = 7,  /* [N, packed_dim] float32 rows: observation | policy_state | achieved_goal |
                             desired_goal | reward | goal_achieved (0/1) | done (0/1); widths in pmg_dims */
     PMG_BUF_STATE = 8,   /* [N, 32] float32 hot state rows (q9 qd9 ee3 jt7 grip elapsed enabled resets) */
-    PMG_BUF_SCHED = 9,   /* [3 + 3N] int32 launch schedule of the last step (diagnostics): n_prone, n_free, prone list [N],
-                            free list [N], n_redo, redo list [N] -- see DESIGN.md "launch-order plan" */
+    PMG_BUF_SCHED = 9,   /* [4 + 3N + 3 ceil(N / 1024)] int32 launch schedule of the last step (diagnostics): n_prone, n_free,
+                            prone list [N], free list [N], n_redo, redo list [N], then the two-pass plan's per-workgroup class
+                            counts and its promotion flag -- see DESIGN.md "launch-order plan" */
     PMG_BUF_ENV_CYCLES = 10 /* [N, 2] int32 (diagnostics; only when the handle was created with PMG_ENV_CYCLES=1 in the
                             environment, PMG_E_INVALID otherwise): shader cycles / 64 the env's wavefront spent in its last
                             step, and the largest contact count any of that step's substeps saw (envs with free objects) */
@@ -114,6 +115,9 @@ int pmg_create(const pmg_config* cfg, pmg_env** out);
 void pmg_destroy(pmg_env* env);
 int pmg_get_dims(const pmg_env* env, pmg_dims* out);
 const char* pmg_last_error(const pmg_env* env); /* env may be NULL: last create error */
+/* HIP devices this process can see (0 when there is none / no driver): lets a rank whose launcher restricted
+ * visibility to one GPU fall back to device 0 instead of LOCAL_RANK (bench.py). */
+int pmg_device_count(void);
 
 /* Replaces: BaseBulletMGEnv.seed (base_env.py:120-122) == gym.utils.seeding.np_random:
  * MT19937 seeded by init_by_array(sha512(str(seed))[:8]) per env. */

@@ -45,12 +45,15 @@ def _p(a):
 class PmgLibrary:
     """A loaded libpmg_hip.so with typed entry points."""
 
-    SYMBOLS = ['pmg_create', 'pmg_destroy', 'pmg_get_dims', 'pmg_last_error', 'pmg_seed', 'pmg_reset', 'pmg_step',
+    SYMBOLS = ['pmg_create', 'pmg_destroy', 'pmg_device_count', 'pmg_get_dims', 'pmg_last_error', 'pmg_seed', 'pmg_reset', 'pmg_step',
                'pmg_reset_device', 'pmg_reset_done_device', 'pmg_step_device', 'pmg_device_ptr', 'pmg_stream', 'pmg_sync', 'pmg_read_outputs',
                'pmg_compute_reward', 'pmg_compute_reward_device', 'pmg_get_state', 'pmg_set_state', 'pmg_set_goal',
                'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_every', 'pmg_timing_read',
                'pmg_device_alloc', 'pmg_device_free', 'pmg_upload', 'pmg_download',
                'pmg_set_sub_goal', 'pmg_curriculum_update', 'pmg_curriculum_read', 'pmg_timing_stats', 'pmg_get_rng', 'pmg_set_rng', 'pmg_comm_timing']
+
+    def device_count(self):
+        return int(self.lib.pmg_device_count())
 
     def __init__(self, path=None):
         self.path = path or DEFAULT_LIBRARY

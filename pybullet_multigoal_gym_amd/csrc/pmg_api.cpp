@@ -431,6 +431,13 @@ void pmg_destroy(pmg_env* e)
     delete e;
 }
 
+int pmg_device_count(void)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return 0;
+    return ndev;
+}
+
 int pmg_get_dims(const pmg_env* e, pmg_dims* out)
 {
     if (!e || !out) return PMG_E_INVALID;
@@ -761,11 +768,13 @@ int pmg_allgather_packed(pmg_env* e, float* d_gathered)
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     size_t count = (size_t)e->dims.num_envs * e->dims.packed_dim;
     if (e->cv_n == EVENT_POOL) drain_comm_events(e);
-    int i = e->cv_n++;
+    /* the event pair counts only once both are recorded: a failed all-gather must not leave a new cv_a paired with a stale cv_b */
+    const int i = e->cv_n;
     HIP_TRY(e, hipEventRecord(e->cv_a[i], e->stream));
     ncclResult_t rc = ncclAllGather(e->P.out, d_gathered, count, ncclFloat, e->comm, e->stream);
     if (rc != ncclSuccess) return fail(e, PMG_E_COMM, "ncclAllGather -> %s", ncclGetErrorString(rc));
     HIP_TRY(e, hipEventRecord(e->cv_b[i], e->stream));
+    e->cv_n = i + 1;
     return PMG_OK;
 }
 

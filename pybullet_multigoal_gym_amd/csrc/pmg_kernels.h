@@ -42,9 +42,10 @@ struct EnvParams {
     float* blocks;   /* [N, BLOCK_DIM * nb] */
     unsigned* rng;   /* [N, 625] MT19937 state + index */
     float* out;      /* [N, packed]: obs | policy | ag | dg | reward | goal_achieved | done */
-    int* sched;      /* [3 + 3N]: counts of {contact-prone, other} envs, the two env lists, then the redo count + list
-                        of the row-packed path (pmg_packed.h); behind it [3 x ceil(N / 1024)] per-workgroup class counts
-                        of the two-pass plan (batches beyond one plan workgroup) */
+    int* sched;      /* [4 + 3N + 3 ceil(N / 1024)]: [0] [1] counts of {contact-prone, other} envs, [2 .. 2 + 2N) the two env
+                        lists, [2 + 2N] the redo count and behind it the redo list of the fast paths (pmg_packed.h); then
+                        [3 + 3N ..) the per-workgroup class counts of the two-pass plan (3 per 1024 envs) and one last word:
+                        did the plan promote the fingers-down class to list 0 (plan_promoted()) */
     int* env_cycles; /* diagnostics (NULL unless PMG_ENV_CYCLES=1 at creation): [N, 2] shader cycles / 64 the env's wavefront spent
                         in its last step, and the largest contact count any of its substeps saw */
 #ifdef PMG_PROFILE

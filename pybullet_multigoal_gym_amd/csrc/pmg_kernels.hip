@@ -25,10 +25,6 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_step(pmg::EnvParam
  * lowest ids and start first), the next ceil(n_free / 4) run the contact-free list four envs per wavefront; the
  * grid is sized for the worst case (N) and its surplus workgroups, all at the END of the dispatch order so that they
  * cannot unbalance the placement of the real ones, exit on their first instruction */
-/* reach, tip control: workgroups [0, n_prone) run the contact-prone list one env per wavefront (the slow waves get the
- * lowest ids and start first), the next ceil(n_free / 4) run the contact-free list four envs per wavefront; the
- * grid is sized for the worst case (N) and its surplus workgroups, all at the END of the dispatch order so that they
- * cannot unbalance the placement of the real ones, exit on their first instruction */
 /* the device-side choice between the two reach kernels: two wavefronts per workgroup as soon as the step has a
  * contact-prone env (a threshold of 1 / 64 of the batch measured worse: one env on the table already sets the step time) */
 /* Registers of the reach kernels.  Two wavefronts per SIMD share the 512-entry unified file: 256 registers each, ArchVGPRs

@@ -80,6 +80,13 @@ __device__ __forceinline__ int lane()
  * moving memory operations across this point -- a wavefront-scope fence plus the (code-less) wave barrier.  No
  * s_barrier: the callers sit in control flow that diverges by row in the packed layout, where a workgroup barrier
  * would be undefined. */
+/* Two-wavefront workgroups count exactly two workgroup barriers per substep on either wavefront (helper_wave_loop): a
+ * build that turns the wave-level fences into __syncthreads, or adds the profile build's barriers to wavefront 0 only,
+ * would pair them up wrongly.  Such builds must switch the two-wave kernels off (tools/prof_k.hip instantiates the
+ * one-wavefront kernels only and says so). */
+#if defined(PMG_LDS_SYNC_BARRIER) && !defined(PMG_NO_TWO_WAVE_KERNELS)
+#error "PMG_LDS_SYNC_BARRIER is incompatible with the two-wavefront workgroups: also define PMG_NO_TWO_WAVE_KERNELS (and PMG_LIST_TWO_WAVES=0)"
+#endif
 __device__ __forceinline__ void lds_sync()
 {
 #ifdef PMG_LDS_SYNC_BARRIER

@@ -8,6 +8,7 @@ deserialises objects from the network), a job token in the hello and rank valida
 """
 import hmac
 import os
+import sys
 import socket
 import struct
 import time
@@ -164,13 +165,22 @@ def _recv(sock, max_payload=MAX_PAYLOAD):
     return _decode(tag, _recv_exact(sock, n))
 
 
-def job_token():
-    """Shared secret of the job's ranks: PMG_RDV_TOKEN if the launcher set one, else derived from what every rank of the
-    job (and nobody who merely found the port) sees in its environment -- the launcher's run id, master address / port
-    and world size."""
+def _is_loopback(addr):
+    return addr in ('localhost', '::1') or addr.startswith('127.')
+
+
+def job_token(addr='127.0.0.1'):
+    """Token the hello of every rank carries.  With PMG_RDV_TOKEN set by the launcher it is a shared secret.  Without it the
+    token is derived from the launcher's run id, master address / port and world size -- values anyone who can reach the
+    port can guess -- so it only rejects STALE or ACCIDENTAL peers (another job, a port scanner), it does not authenticate.
+    That is acceptable on a loopback rendezvous (one node, the only case bench.py launches); on any other bind address
+    PMG_RDV_TOKEN is REQUIRED and its absence is an error."""
     import hashlib
     tok = os.environ.get('PMG_RDV_TOKEN')
     if tok is None:
+        if not _is_loopback(addr):
+            raise RuntimeError('rendezvous on %s: set PMG_RDV_TOKEN to a secret shared by the ranks (the derived token only '
+                               'protects a loopback rendezvous against stale peers)' % addr)
         tok = '|'.join(os.environ.get(k, '') for k in ('TORCHELASTIC_RUN_ID', 'MASTER_ADDR', 'MASTER_PORT', 'PMG_RDV_PORT', 'WORLD_SIZE'))
     return hashlib.sha256(('pmg-rdv:' + tok).encode()).digest()
 
@@ -198,23 +208,49 @@ class Rendezvous:
             srv.listen(self.world)
             srv.settimeout(timeout)
             by_rank = {}
-            token = job_token()
+            token = job_token(addr)
             deadline = time.time() + timeout
+            rejected = []
+
+            def give_up(why):
+                srv.close()
+                for c in by_rank.values():          # do not leave the ranks that did arrive hanging on an open socket
+                    c.close()
+                raise TimeoutError('rendezvous: %d of %d ranks arrived within %.0f s (%s)%s' % (
+                    len(by_rank) + 1, self.world, timeout, why,
+                    '; rejected peers: ' + '; '.join(rejected[-8:]) if rejected else ''))
             while len(by_rank) < self.world - 1:
-                if time.time() > deadline:
-                    srv.close()
-                    raise TimeoutError('rendezvous: %d of %d ranks arrived within %.0f s' % (len(by_rank) + 1, self.world, timeout))
-                conn, _ = srv.accept()
+                left = deadline - time.time()
+                if left <= 0:
+                    give_up('deadline')
+                srv.settimeout(min(left, 5.0))
+                try:
+                    conn, peer = srv.accept()
+                except socket.timeout:
+                    continue
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(10.0)
+                conn.settimeout(2.0)                # an idle stranger holds the accept loop for 2 s, not 10
+                why = None
                 try:      # hello = [token bytes, rank]; anything else (a port scanner, a stale job) is dropped, not fatal
                     hello = _recv(conn, max_payload=256)
-                    good = (isinstance(hello, list) and len(hello) == 2 and isinstance(hello[0], bytes)
-                            and hmac.compare_digest(hello[0], token) and isinstance(hello[1], int)
-                            and 1 <= hello[1] < self.world and hello[1] not in by_rank)
-                except (ConnectionError, OSError, struct.error, ValueError):
-                    good = False
-                if not good:
+                    if not (isinstance(hello, list) and len(hello) == 2 and isinstance(hello[0], bytes) and isinstance(hello[1], int)):
+                        why = 'malformed hello'
+                    elif not hmac.compare_digest(hello[0], token):
+                        why = 'wrong job token (do the ranks share PMG_RDV_TOKEN / MASTER_ADDR / MASTER_PORT / WORLD_SIZE?)'
+                    elif not 1 <= hello[1] < self.world:
+                        why = 'rank %d out of range' % hello[1]
+                    elif hello[1] in by_rank:
+                        why = 'duplicate rank %d' % hello[1]
+                except (ConnectionError, OSError, struct.error, ValueError) as ex:
+                    why = 'unreadable hello (%s)' % type(ex).__name__
+                if why is not None:
+                    msg = '%s:%s %s' % (peer[0], peer[1], why)
+                    rejected.append(msg)
+                    print('rendezvous (rank 0): dropped a connection from ' + msg, file=sys.stderr, flush=True)
+                    try:
+                        _send(conn, ['NAK', why])   # a legitimate rank fails fast with the reason instead of timing out
+                    except (ConnectionError, OSError):
+                        pass
                     conn.close()
                     continue
                 conn.settimeout(timeout)
@@ -233,7 +269,7 @@ class Rendezvous:
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            _send(s, [job_token(), self.rank])
+            _send(s, [job_token(addr), self.rank])
             self.sock = s
 
     @classmethod
@@ -250,7 +286,10 @@ class Rendezvous:
                 _send(c, out)
             return out
         _send(self.sock, obj)
-        return _recv(self.sock)
+        out = _recv(self.sock)
+        if isinstance(out, list) and len(out) == 2 and isinstance(out[0], str) and out[0] == 'NAK' and isinstance(out[1], str):
+            raise ConnectionError('rendezvous: rank 0 refused this rank: ' + out[1])
+        return out
 
     def broadcast(self, obj, src=0):
         return self.allgather(obj if self.rank == src else None)[src]

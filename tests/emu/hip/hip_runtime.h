@@ -17,7 +17,8 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
 
 static inline const char* hipGetErrorString(hipError_t) { return "emulated hip error"; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 8; return hipSuccess; } /* ranks of a multi-process test each pick "their" device */
+/* ranks of a multi-process test each pick "their" device; PMG_EMU_DEVICES=1 plays a launcher that shows every rank one GPU */
+static inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("PMG_EMU_DEVICES"); *n = e ? atoi(e) : 8; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; } /* an MI355X */

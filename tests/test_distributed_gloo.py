@@ -121,6 +121,33 @@ def test_bench_multi_rank_control_flow(built, launcher, force_fail):
     assert 'no torch' in out.stderr
 
 
+def test_bench_eight_ranks_on_the_emulator(built):
+    """`python bench.py --gpus 8` end to end on the emulator build -- what the driver's SCALE run executes on an 8-GPU node:
+    eight ranks rendezvous, the communicator comes up, one all-gather per step, per_rank carries eight entries, value is the
+    slowest rank's.  The ranks see ONE device each here (PMG_EMU_DEVICES=1, as under a launcher that restricts visibility
+    per rank): every rank must fall back from device LOCAL_RANK to device 0."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--envs-per-gpu', '2', '--no-extras',
+           '--episode-steps', '2', '--lib', os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so')]
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env['PMG_ASSERT_NO_TORCH'] = '1'
+    env['PMG_EMU_DEVICES'] = '1'
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['global_envs'] == 16 and 'FALLBACK' not in d['config']['parallelism']
+    pr = d['per_rank']
+    for k in ('ms_per_step', 'kernel_ms', 'allgather_ms', 'allgather_launches', 'host_gather_ms'):
+        assert len(pr[k]) == 8, k
+    assert pr['allgather_launches'] == [2] * 8 and 0 <= pr['slowest_rank'] < 8
+    assert max(pr['ms_per_step']) <= d['ms_per_step'] * 1.0001 + 1e-6
+    assert out.stderr.count('using device 0') >= 7                  # ranks 1..7 fell back from device LOCAL_RANK
+
+
 def test_rendezvous_drops_strangers_and_never_unpickles(built):
     """Rank 0's listener: a connection that sends garbage, a pickle, an oversized length or the wrong job token is dropped
     (not fatal, nothing deserialised), a duplicate or out-of-range rank is refused, and the real peer still gets in."""
@@ -149,7 +176,8 @@ def test_rendezvous_drops_strangers_and_never_unpickles(built):
         s.sendall(payload)
         s.settimeout(2.0)
         try:
-            assert s.recv(16) == b''            # closed on us, no reply
+            reply = s.recv(256)                 # closed on us; at most a NAK frame naming the reason (a rank with the wrong
+            assert reply == b'' or (reply.startswith(D.MAGIC) and b'NAK' in reply)   # token fails fast instead of timing out)
         except (ConnectionError, socket.timeout):
             pass
         s.close()

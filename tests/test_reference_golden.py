@@ -90,15 +90,26 @@ def _float32_floor(fx):
         env.close()
 
 
+# sessions whose float32 ORACLE already strays > 3e-4 (positions) / 1.5e-3 (observations incl. velocities) from the float64
+# fixture over a whole episode: fingers scraping the table under joint control, blocks rubbing along the chest's door
+RELAXED = {'ref_block_rearrange3.json', 'ref_chest_push2.json', 'ref_chest_push2_decomp.json', 'ref_chest_push3_curriculum_grip.json',
+           'ref_chest_push3_grip_decomp.json', 'ref_push.json', 'ref_slide.json'}   # all on the velocity columns: 4.9e-3 .. 5.2e-3
+
+
 def _replay_whole_episodes(path, library):
     fx = R.load(path)
     bars = dict(GPU_BARS.get(fx['task'], GPU_DEFAULT))
     floor = _float32_floor(fx)
     guard = 2e-3
+    name = os.path.basename(path)
     if floor['traj'] > 3e-4 or floor['obs'] > 1.5e-3:      # bifurcation in float32 itself (see above)
-        bars['tol_traj'] = max(bars['tol_traj'], 2 * floor['traj'])
-        bars['tol_vel'] = max(bars['tol_vel'], 2 * floor['obs'])
-        guard = max(guard, 2 * floor['traj'])
+        # the relaxed bar is CAPPED (positions 5e-3, velocities 2e-2) and only the sessions listed in RELAXED may take it:
+        # a new float32 bifurcation shows up as a failure here instead of being absorbed by a bar that follows it
+        assert name in RELAXED, '%s: the float32 oracle strays %s from the fixture -- a session that is not on the RELAXED list' % (name, floor)
+        bars['tol_traj'] = min(max(bars['tol_traj'], 2 * floor['traj']), max(bars['tol_traj'], 5e-3))
+        bars['tol_vel'] = min(max(bars['tol_vel'], 2 * floor['obs']), max(bars['tol_vel'], 2e-2))
+        guard = min(max(guard, 2 * floor['traj']), 5e-3)
+        print('RELAXED-BAR session', name, floor)
     env = R.ProductAdapter(fx, library=library)
     worst = R.replay(fx, env, tol_static=2e-5, threshold_guard=guard, traj_steps=None, **bars)
     env.close()

@@ -43,7 +43,8 @@ for d in sorted(glob.glob(os.path.join(src, 'pmc_*'))):
 sys.path.insert(0, root)
 import bench  # noqa: E402  (kernel_source_hash: ties the pass to the kernel sources that were profiled)
 SRC = bench.kernel_source_hash()
-summary_out = dict(summary, _stamp={'kernel_source_sha16': SRC, 'tag': tag})
+LIB = bench.library_hash()
+summary_out = dict(summary, _stamp={'kernel_source_sha16': SRC, 'library_sha16': LIB, 'tag': tag})
 json.dump(summary_out, open(os.path.join(dst, '%s_%s%d_pmc_summary.json' % (tag, task, N)), 'w'), indent=1, sort_keys=True)
 if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
     fk, wk = summary['FETCH_SIZE']['mean_per_launch'], summary['WRITE_SIZE']['mean_per_launch']
@@ -57,7 +58,7 @@ if 'FETCH_SIZE' in summary and 'WRITE_SIZE' in summary:
             if c.get('fetch_factor_dword') and c.get('write_factor_dword'):
                 cal = {'fetch_dword': c['fetch_factor_dword'], 'write_dword': c['write_factor_dword'], 'source': os.path.basename(cand)}
                 break
-    json.dump({'task': task, 'envs_per_gpu': N, 'kernel_source_sha16': SRC,
+    json.dump({'task': task, 'envs_per_gpu': N, 'kernel_source_sha16': SRC, 'library_sha16': LIB,
                'command': 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --output-format csv -- python bench.py --task %s --envs-per-gpu %d --steps 50 --warmup 5 --no-cpu-baseline --no-extras' % (task, N),
                'kernel': 'pmg_k_step family (+ redo)', 'FETCH_SIZE_KiB': fk, 'WRITE_SIZE_KiB': wk, 'calibration': cal,
                'hbm_bytes_per_launch': (fk * cal['fetch_dword'] + wk * cal['write_dword']) * 1024.0,
