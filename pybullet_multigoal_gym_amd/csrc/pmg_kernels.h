@@ -248,7 +248,7 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
             if (SIMPLE) {
                 const float z = in[k].ee[2], zn = fminf(fmaxf(z + in[k].a[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
                 cls = fminf(z, zn) < P.ee_lo[2] + 0.012f ? 0 : 1;        /* = plan_class for nb == 0, tip control */
-            } else cls = plan_class(P, actions, env, in[k]);
+            } else cls = plan_class(P, actions, env < P.n_envs ? env : 0, in[k]);   /* (lanes beyond the batch classify env 0: no read past the buffers) */
             cls = env < P.n_envs ? cls : 3;
             clsbits |= (unsigned)cls << (2 * (c0 + k));
         }
