@@ -141,44 +141,46 @@ __global__ void __launch_bounds__(256) pmg_k_reward3(const float4* __restrict__ 
     }
 }
 /* multi-block goals (G = 3 * num_block, up to 19 with the gripper tail): a workgroup owns 256 consecutive items = one
- * contiguous span of 256 * G floats per array.  Its threads read that span FLAT (lane = consecutive 16-byte / 4-byte
- * words: fully coalesced whatever G is), leave the partial sums of squares of their words in LDS, and thread t then adds
- * the G / VEC partials of item t (stride G / VEC, odd for every G here: conflict-free) and stores one reward and one
- * flag, contiguously.  VEC = 4 when G is a multiple of 4 (block_stack-4: G = 12), else 1. */
-template <int VEC>
+ * contiguous span of 256 * G floats = 64 * G float4 per array WHATEVER G is.  Its threads read that span flat as float4
+ * (lane = consecutive 16 bytes: fully coalesced, non-temporal), every load of a thread in flight before the first use,
+ * and leave the four squared differences of each float4 in LDS; thread t then adds the G squares of item t (stride G) and
+ * stores one reward and one flag, contiguously.  One workgroup per 256 items, no grid-stride below 2^20 workgroups.
+ * Measured (tools/reward_flat_variants.hip, 16 Mi pairs, G = 7 / 9 / 12 / 13 / 16 / 19): 6.0-6.1 TB/s at every G against
+ * 5.2-5.6 for round 3's kernel (dword loads when G % 4 != 0, loads issued one per loop trip, 8192 workgroups striding);
+ * partial sums per float4 when G % 4 == 0 (less LDS traffic) measured 5.9, flags packed into dwords the same as bytes. */
 __global__ void __launch_bounds__(256) pmg_k_reward_flat(const float* __restrict__ ag, const float* __restrict__ dg, long long B, int G,
                                                         float thr, int binary, float* __restrict__ reward,
                                                         unsigned char* __restrict__ ok)
 {
-    __shared__ float part[256 * 20];
+    constexpr int MAXQ = 5;                                    /* float4 per thread per array: G <= 20 */
+    __shared__ float4 sq[MAXQ * 256];
     const int t = (int)threadIdx.x;
-    const int wpi = G / VEC;                                   /* words per item */
-    for (long long base = (long long)blockIdx.x * 256; base < B; base += (long long)gridDim.x * 256) {
-        const long long items = B - base < 256 ? B - base : 256;
-        const long long words = items * wpi;
-        const float* a = ag + base * G;
-        const float* d = dg + base * G;
-        for (long long w = t; w < words; w += 256) {
-            float s;
-            if (VEC == 4) {
-                float4 x = ((const float4*)a)[w], y = ((const float4*)d)[w];   /* (non-temporal loads measured SLOWER here: 5.31 vs 5.49-5.70 TB/s at G = 12) */
-                float e0 = x.x - y.x, e1 = x.y - y.y, e2 = x.z - y.z, e3 = x.w - y.w;
-                s = (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-            } else {
-                float e = a[w] - d[w];
-                s = e * e;
+    const int q4 = G * 64;                                     /* float4 per array of a full workgroup */
+    for (long long base = (long long)blockIdx.x * 256; base + 256 <= B; base += (long long)gridDim.x * 256) {
+        const float4* a = (const float4*)(ag + base * G);
+        const float4* d = (const float4*)(dg + base * G);
+        float4 x[MAXQ], y[MAXQ];
+#pragma unroll
+        for (int k = 0; k < MAXQ; k++) {
+            const int w = t + 256 * k;
+            if (w < q4) { x[k] = nt::load4(a + w); y[k] = nt::load4(d + w); }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXQ; k++) {
+            const int w = t + 256 * k;
+            if (w < q4) {
+                const float e0 = x[k].x - y[k].x, e1 = x[k].y - y[k].y, e2 = x[k].z - y[k].z, e3 = x[k].w - y[k].w;
+                sq[w] = make_float4(e0 * e0, e1 * e1, e2 * e2, e3 * e3);
             }
-            part[w] = s;
         }
         __syncthreads();
-        if (t < items) {
-            float s = 0.f;
-            for (int k = 0; k < wpi; k++) s += part[t * wpi + k];
-            float dist = sqrtf(s);
-            bool na = dist > thr;
-            if (reward) reward[base + t] = binary ? (na ? -1.f : -0.f) : -dist;
-            if (ok) ok[base + t] = na ? 0 : 1;
-        }
+        const float* part = (const float*)sq + t * G;
+        float s = 0.f;
+        for (int k = 0; k < G; k++) s += part[k];
+        const float dist = sqrtf(s);
+        const bool na = dist > thr;
+        if (reward) reward[base + t] = binary ? (na ? -1.f : -0.f) : -dist;
+        if (ok) ok[base + t] = na ? 0 : 1;
         __syncthreads();
     }
 }
@@ -397,13 +399,12 @@ hipError_t pmg_launch_reward(const float* ag, const float* dg, long long B, int 
                            (float4*)reward, (unsigned int*)ok);
         first = quads * 4;
     }
-    if (G > 3 && G <= 20 && B >= 256) {
-        long long want = (B + 255) / 256;
-        unsigned grid = (unsigned)(want < 8192 ? want : 8192);
-        bool vec4 = (G % 4 == 0) && ((((size_t)ag | (size_t)dg) & 15) == 0);
-        if (vec4) hipLaunchKernelGGL((pmg_k_reward_flat<4>), dim3(grid), dim3(256), 0, s, ag, dg, B, G, thr, binary, reward, ok);
-        else hipLaunchKernelGGL((pmg_k_reward_flat<1>), dim3(grid), dim3(256), 0, s, ag, dg, B, G, thr, binary, reward, ok);
-        first = B;
+    static const int generic_only = getenv("PMG_REWARD_GENERIC") ? atoi(getenv("PMG_REWARD_GENERIC")) : 0;   /* (counter calibration: the dword kernel) */
+    if (G > 3 && G <= 20 && B >= 256 && ((((size_t)ag | (size_t)dg) & 15) == 0) && !generic_only) {
+        long long want = B / 256;                                /* full workgroups; the < 256 tail items go to pmg_k_reward */
+        unsigned grid = (unsigned)(want < (1 << 20) ? want : (1 << 20));
+        hipLaunchKernelGGL(pmg_k_reward_flat, dim3(grid), dim3(256), 0, s, ag, dg, B, G, thr, binary, reward, ok);
+        first = want * 256;
     }
     if (first < B) {
         unsigned grid = (unsigned)((B - first + 255) / 256);

@@ -695,14 +695,16 @@ def test_small_contact_store_overflow_goes_through_redo_multi(built):
     env.close()
 
 
-@pytest.mark.parametrize('kw,G', [({'num_block': 4}, 12), ({'num_block': 3}, 9), ({'num_block': 3, 'grip_informed_goal': True}, 13)])
+@pytest.mark.parametrize('kw,G', [({'num_block': 4}, 12), ({'num_block': 3}, 9), ({'num_block': 3, 'grip_informed_goal': True}, 13),
+                                  ({'num_block': 4, 'grip_informed_goal': True}, 16), ({'num_block': 5, 'grip_informed_goal': True}, 19)])
 def test_compute_reward_batch_multi_block_goals(built, kw, G):
-    """HER relabelling batches with multi-block goal vectors go through the flat coalesced kernel (float4 words when G
-    is a multiple of 4); sizes that are not a multiple of the 256-item workgroup span exercise the ragged tail."""
+    """HER relabelling batches with multi-block goal vectors go through the flat coalesced kernel (the 256-item span of a
+    workgroup read as float4 words whatever G is); sizes that are not a multiple of 256 leave their tail to the generic
+    kernel."""
     env = pmg.make_env(task='block_stack', num_envs=4, **kw)
     assert env.dims.goal_dim == G
     rs = np.random.RandomState(0)
-    for B in (1000, 256, 257, 5):
+    for B in (1000, 256, 257, 5, 70000):
         ag = rs.uniform(-0.1, 0.1, (B, G)).astype(np.float32)
         dg = (ag + rs.uniform(-0.03, 0.03, (B, G))).astype(np.float32)
         r, ok = env._compute_reward(ag, dg)
