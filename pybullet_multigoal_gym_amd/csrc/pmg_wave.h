@@ -187,6 +187,67 @@ __device__ __forceinline__ void bcastn_r0(const float* v, int src, float* out)
     for (int k = 0; k < N; k++) out[k] = bcast_r0(v[k], src);
 }
 
+/* Row-local fused broadcast arithmetic of the mass-matrix code (CRBA entries, Gauss-Jordan): the lane-SRC operand rides on
+ * the DPP port of the multiply-add itself (row_newbcast) -- the compiler leaves most such broadcasts as a v_mov_b32_dpp in
+ * front of the fma (475 of them in the reach kernel).  One s_nop 1 per block: the 2 wait states a DPP read needs after a
+ * VALU write of its source, which the hazard recognizer cannot see through the asm (tools/check_dpp_hazards.py checks the
+ * shipped binary). */
+/* sum_a v[a](lane SRC of my row) * c[a], a < 6, summed in index order */
+template <int SRC>
+__device__ __forceinline__ float dot6_bcast_r0_c(const float* v, const float* c)
+{
+#if !defined(PMG_NO_R0_DPP) && !defined(PMG_NO_DPP_FMAC)
+    float acc;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %7 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %2, %8 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %3, %9 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %4, %10 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %5, %11 row_newbcast:%13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %6, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+        : "=&v"(acc)
+        : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "n"(SRC));
+    return acc;
+#else
+    float acc = bcast_r0_c<SRC>(v[0]) * c[0];
+#pragma unroll
+    for (int a = 1; a < 6; a++) acc = fmaf(bcast_r0_c<SRC>(v[a]), c[a], acc);
+    return acc;
+#endif
+}
+/* a[j] += f * a[j](lane P of my row) for the eight j != P of a nine-entry row, j = P+1 first (the next pivot's column is the
+ * oldest write when the next block reads it) */
+template <int P>
+__device__ __forceinline__ void gj9_eliminate_r0_c(float* a, float f)
+{
+#if !defined(PMG_NO_R0_DPP) && !defined(PMG_NO_DPP_FMAC)
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %6, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %7, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(a[(P + 1) % 9]), "+v"(a[(P + 2) % 9]), "+v"(a[(P + 3) % 9]), "+v"(a[(P + 4) % 9]), "+v"(a[(P + 5) % 9]), "+v"(a[(P + 6) % 9]),
+          "+v"(a[(P + 7) % 9]), "+v"(a[(P + 8) % 9])
+        : "v"(f), "n"(P));
+#else
+#pragma unroll
+    for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast_r0_c<P>(a[j]), f, a[j]); }
+#endif
+}
+/* 1 / x by the hardware reciprocal (1 ulp; the compiler's 2.5-ulp division is a frexp / rcp / ldexp sequence of six) */
+__device__ __forceinline__ float rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.f / x;
+#endif
+}
+
 template <int CTRL>
 __device__ __forceinline__ float dpp(float old, float v)
 {
@@ -398,6 +459,11 @@ template <int N>
 __device__ __forceinline__ void bcastn_r0(const float* v, int src, float* out) { bcastn<N>(v, src, out); }
 template <int SRC>
 __device__ __forceinline__ void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2) { fma2_bcast_c<SRC>(v, c1, acc1, c2, acc2); }
+template <int SRC>
+__device__ __forceinline__ float dot6_bcast_r0_c(const float* v, const float* c) { return wv::dot6_bcast_r0_c<SRC>(v, c); }   /* (row_newbcast is row-local) */
+template <int P>
+__device__ __forceinline__ void gj9_eliminate_r0_c(float* a, float f) { wv::gj9_eliminate_r0_c<P>(a, f); }
+__device__ __forceinline__ float rcp(float x) { return wv::rcp(x); }
 template <int N>
 __device__ __forceinline__ float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }
 template <int N>

@@ -178,6 +178,19 @@ template <int N>
 inline void bcastn_r0(const float* v, int src, float* out) { bcastn<N>(v, src, out); }
 template <int SRC>
 inline void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2) { fma2_bcast_c<SRC>(v, c1, acc1, c2, acc2); }
+template <int SRC>
+inline float dot6_bcast_r0_c(const float* v, const float* c)
+{
+    float acc = bcast(v[0], SRC) * c[0];
+    for (int a = 1; a < 6; a++) acc = fmaf(bcast(v[a], SRC), c[a], acc);
+    return acc;
+}
+template <int P>
+inline void gj9_eliminate_r0_c(float* a, float f)
+{
+    for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
+}
+inline float rcp(float x) { return 1.f / x; }
 }  // namespace wv
 
 /* row-packed variant (four envs per wave, one per 16-lane row): see the product header.  The fiber scheduler
@@ -261,5 +274,18 @@ template <int N>
 inline void bcastn_r0(const float* v, int src, float* out) { bcastn<N>(v, src, out); }
 template <int SRC>
 inline void fma2_bcast_r0_c(float v, float c1, float& acc1, float c2, float& acc2) { fma2_bcast_c<SRC>(v, c1, acc1, c2, acc2); }
+template <int SRC>
+inline float dot6_bcast_r0_c(const float* v, const float* c)
+{
+    float acc = bcast(v[0], SRC) * c[0];
+    for (int a = 1; a < 6; a++) acc = fmaf(bcast(v[a], SRC), c[a], acc);
+    return acc;
+}
+template <int P>
+inline void gj9_eliminate_r0_c(float* a, float f)
+{
+    for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
+}
+inline float rcp(float x) { return 1.f / x; }
 }  // namespace wr
 #endif
