@@ -52,8 +52,12 @@ __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst
     PMGP_T(3);
     float rq = l < NJ ? tau - h : 0.f;
     float qdd = 0.f;
+#if PMG_FMA9
+    qdd = wr::fma9_lanes_r0(qdd, minv, rq);
+#else
 #pragma unroll
     for (int j = 0; j < NJ; j++) qdd += minv[j] * wr::bcast_r0(rq, j);
+#endif
     qd += DT * qdd;
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);

@@ -191,6 +191,18 @@ inline void gj9_eliminate_r0_c(float* a, float f)
     for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
 }
 inline float rcp(float x) { return 1.f / x; }
+inline float fsqrt(float x) { return sqrtf(x); }
+inline float fma9_lanes_r0(float acc, const float* c, float v)
+{
+    for (int j = 0; j < 9; j++) acc = fmaf(bcast(v, j), c[j], acc);
+    return acc;
+}
+inline float add_shr2_bank2(float y, float x)
+{
+    const float y2 = row_shr<2>(y, 0.f);
+    const int rl = (int)threadIdx.x & 15;
+    return (rl >= 8 && rl < 12) ? y2 + x : y;
+}
 }  // namespace wv
 
 /* row-packed variant (four envs per wave, one per 16-lane row): see the product header.  The fiber scheduler
@@ -287,5 +299,17 @@ inline void gj9_eliminate_r0_c(float* a, float f)
     for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
 }
 inline float rcp(float x) { return 1.f / x; }
+inline float fsqrt(float x) { return sqrtf(x); }
+inline float fma9_lanes_r0(float acc, const float* c, float v)
+{
+    for (int j = 0; j < 9; j++) acc = fmaf(bcast(v, j), c[j], acc);
+    return acc;
+}
+inline float add_shr2_bank2(float y, float x)
+{
+    const float y2 = row_shr<2>(y, 0.f);
+    const int rl = (int)threadIdx.x & 15;
+    return (rl >= 8 && rl < 12) ? y2 + x : y;
+}
 }  // namespace wr
 #endif
