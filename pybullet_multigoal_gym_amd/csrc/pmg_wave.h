@@ -294,6 +294,49 @@ __device__ __forceinline__ float fma9_lanes_r0(float acc, const float* c, float 
     return acc;
 #endif
 }
+/* One Gauss-Jordan pivot of a 6 x 6 system [A | e], lane a < 6 = row a (the IK's damped least squares): every row loses
+ * f x row_P in its five other columns and its right-hand side, f as in gj9_eliminate_r0_c */
+template <int P>
+__device__ __forceinline__ void gj6_eliminate_r0_c(float* a, float& e, float f)
+{
+#if !defined(PMG_NO_R0_DPP) && !defined(PMG_NO_DPP_FMAC)
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %4, %4, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %5, %5, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+        : "+v"(a[(P + 1) % 6]), "+v"(a[(P + 2) % 6]), "+v"(a[(P + 3) % 6]), "+v"(a[(P + 4) % 6]), "+v"(a[(P + 5) % 6]), "+v"(e)
+        : "v"(f), "n"(P));
+#else
+#pragma unroll
+    for (int k = 1; k < 6; k++) { const int j = (P + k) % 6; a[j] = fmaf(bcast_r0_c<P>(a[j]), f, a[j]); }
+    e = fmaf(bcast_r0_c<P>(e), f, e);
+#endif
+}
+/* sum_a c[a] * v(lane a of my row), a < 6 */
+__device__ __forceinline__ float dot6_lanes_r0(const float* c, float v)
+{
+#if !defined(PMG_NO_R0_DPP) && !defined(PMG_NO_DPP_FMAC)
+    float acc;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+        : "=&v"(acc)
+        : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]));
+    return acc;
+#else
+    float acc = bcast_r0_c<0>(v) * c[0];
+    acc = fmaf(bcast_r0_c<1>(v), c[1], acc); acc = fmaf(bcast_r0_c<2>(v), c[2], acc); acc = fmaf(bcast_r0_c<3>(v), c[3], acc);
+    acc = fmaf(bcast_r0_c<4>(v), c[4], acc); acc = fmaf(bcast_r0_c<5>(v), c[5], acc);
+    return acc;
+#endif
+}
 /* lanes 8..11 of every row: y <- y(lane l - 2) + x; the other lanes keep y (the finger-2 step of chain_prefix) */
 __device__ __forceinline__ float add_shr2_bank2(float y, float x)
 {
@@ -545,6 +588,9 @@ __device__ __forceinline__ float dot6_bcast_r0_c(const float* v, const float* c)
 template <int P>
 __device__ __forceinline__ void gj9_eliminate_r0_c(float* a, float f) { wv::gj9_eliminate_r0_c<P>(a, f); }
 __device__ __forceinline__ float rcp(float x) { return wv::rcp(x); }
+template <int P>
+__device__ __forceinline__ void gj6_eliminate_r0_c(float* a, float& e, float f) { wv::gj6_eliminate_r0_c<P>(a, e, f); }
+__device__ __forceinline__ float dot6_lanes_r0(const float* c, float v) { return wv::dot6_lanes_r0(c, v); }
 __device__ __forceinline__ float fsqrt(float x) { return wv::fsqrt(x); }
 __device__ __forceinline__ float fma9_lanes_r0(float acc, const float* c, float v) { return wv::fma9_lanes_r0(acc, c, v); }
 __device__ __forceinline__ float add_shr2_bank2(float y, float x) { return wv::add_shr2_bank2(y, x); }

@@ -191,6 +191,18 @@ inline void gj9_eliminate_r0_c(float* a, float f)
     for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
 }
 inline float rcp(float x) { return 1.f / x; }
+template <int P>
+inline void gj6_eliminate_r0_c(float* a, float& e, float f)
+{
+    for (int k = 1; k < 6; k++) { const int j = (P + k) % 6; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
+    e = fmaf(bcast(e, P), f, e);
+}
+inline float dot6_lanes_r0(const float* c, float v)
+{
+    float acc = bcast(v, 0) * c[0];
+    for (int a = 1; a < 6; a++) acc = fmaf(bcast(v, a), c[a], acc);
+    return acc;
+}
 inline float fsqrt(float x) { return sqrtf(x); }
 inline float fma9_lanes_r0(float acc, const float* c, float v)
 {
@@ -299,6 +311,18 @@ inline void gj9_eliminate_r0_c(float* a, float f)
     for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
 }
 inline float rcp(float x) { return 1.f / x; }
+template <int P>
+inline void gj6_eliminate_r0_c(float* a, float& e, float f)
+{
+    for (int k = 1; k < 6; k++) { const int j = (P + k) % 6; a[j] = fmaf(bcast(a[j], P), f, a[j]); }
+    e = fmaf(bcast(e, P), f, e);
+}
+inline float dot6_lanes_r0(const float* c, float v)
+{
+    float acc = bcast(v, 0) * c[0];
+    for (int a = 1; a < 6; a++) acc = fmaf(bcast(v, a), c[a], acc);
+    return acc;
+}
 inline float fsqrt(float x) { return sqrtf(x); }
 inline float fma9_lanes_r0(float acc, const float* c, float v)
 {
