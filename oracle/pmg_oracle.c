@@ -1001,14 +1001,137 @@ static void closest_on_cyl(const real* cc, const real* a, real rad, real hl, con
     real sc = rl > rad ? rad / rl : 1;
     for (int x = 0; x < 3; x++) q[x] = cc[x] + ta * a[x] + sc * r[x];
 }
+/* The deepest point of a box FACE under a tilted cap that is neither a face corner inside the disc nor a rim point over
+ * the face: where an edge of the face crosses the cap's rim (seen along the cylinder axis).  The height above the cap
+ * plane is linear over the face, so its extreme over face x disc sits at a corner, at the lowest rim point or at such a
+ * crossing -- the candidate the clipped feature points lacked (a contact found up to 1.7 mm late at <= 3 degrees of tilt,
+ * tests/test_oracle_physics.py).  fc: face centre, (B1, h1), (B2, h2): its in-plane axes; pc: cap centre, a: cylinder
+ * axis; the contact normal n, can = a . n.  Of the <= 8 crossings the one with the smallest separation t along n (box
+ * point q, cylinder point q + t n in the cap plane) is returned; 0 if no edge crosses the rim. */
+static int face_rim_crossing(const real* fc, const real* B1, real h1, const real* B2, real h2, const real* pc, const real* a,
+                             real rad, const real* n, real can, real* q, real* tq)
+{
+    int found = 0;
+    real bt = 0;
+    for (int e = 0; e < 4; e++) {
+        const real* E = e < 2 ? B2 : B1;                 /* edge direction; the edge sits at +-h of the OTHER axis */
+        const real* F = e < 2 ? B1 : B2;
+        real he = e < 2 ? h2 : h1, hf = (e & 1) ? (e < 2 ? h1 : h2) : -(e < 2 ? h1 : h2);
+        real w0[3];
+        for (int x = 0; x < 3; x++) w0[x] = fc[x] + hf * F[x] - pc[x];
+        real Ea = v3dot(E, a), wa = v3dot(w0, a);
+        real qa = 1 - Ea * Ea, qb = v3dot(w0, E) - wa * Ea, qc = v3dot(w0, w0) - wa * wa - rad * rad;
+        real disc = qb * qb - qa * qc;
+        if (qa < (real)1e-9 || disc < 0) continue;
+        real sq = RSQRT(disc);
+        for (int r2 = 0; r2 < 2; r2++) {
+            real t = (-qb + (r2 ? sq : -sq)) / qa;
+            if (RFABS(t) > he) continue;
+            real pt[3];
+            for (int x = 0; x < 3; x++) pt[x] = w0[x] + t * E[x];      /* relative to the cap centre */
+            real ts = -v3dot(pt, a) / can;
+            if (!found || ts < bt) { found = 1; bt = ts; for (int x = 0; x < 3; x++) q[x] = pt[x] + pc[x]; }
+        }
+    }
+    *tq = bt;
+    return found;
+}
+#ifndef CLOSEST_BLOCKS
+#define CLOSEST_BLOCKS 3
+#endif
 /* mutual closest points of the cylinder and the box by alternating projections (disjoint convex sets) */
+static void closest_rounds(const real* cc, const real* a, real rad, real hl, const real* cb, const real (*B)[3],
+                           const real* hb, real* qc, real* p0)
+{
+    /* Alternating projections crawl when the two nearest features are almost parallel (a cap over a face tilted by 3 degrees
+     * contracts by ~0.3 % per round).  The crawl is a geometric sequence along a fixed direction, so after every block of
+     * six rounds the box point is extrapolated to the limit of that sequence (step ratio rho of the last two moves:
+     * + move * rho / (1 - rho), rho capped at 0.995), put back on the box, and the rounds go on from there. */
+    for (int blk = 0; blk < CLOSEST_BLOCKS; blk++) {
+        real d1 = 0, d2 = 0, w[3] = {0, 0, 0};
+        for (int it = 0; it < 6; it++) {
+            real pn[3];
+            closest_on_cyl(cc, a, rad, hl, p0, qc);
+            closest_on_box(cb, B, hb, qc, pn);
+            v3sub(w, pn, p0);
+            v3cpy(p0, pn);
+            d1 = d2; d2 = v3norm(w);
+        }
+        if (blk == CLOSEST_BLOCKS - 1 || d2 < (real)1e-7 || d1 <= d2) break;
+        real rho = d2 / d1;
+        if (rho > (real)0.995) rho = (real)0.995;
+        real pj[3], pb[3], qj[3], e0[3], e1[3];
+        v3cpy(pj, p0); v3axpy(pj, rho / (1 - rho), w);
+        closest_on_box(cb, B, hb, pj, pb);
+        closest_on_cyl(cc, a, rad, hl, pb, qj);
+        closest_on_cyl(cc, a, rad, hl, p0, qc);
+        v3sub(e0, qc, p0); v3sub(e1, qj, pb);
+        if (v3dot(e1, e1) < v3dot(e0, e0)) v3cpy(p0, pb);        /* taken only when it brings the pair closer */
+    }
+    /* (qc, p0 = the box's closest point to qc: their difference is a normal of the box at p0 -- the supporting direction
+     * the axis test wants -- whether the rounds have settled or not) */
+    {   /* p0 on an EDGE of the box (two coordinates at their extents): the rim of a tilted cap against that edge is the slowest
+         * crawl of all, and a one-dimensional problem -- the squared distance to the cylinder is convex along the edge and
+         * its derivative is (x - closest(x)) . E: eight regula-falsi (Illinois) steps on it */
+        real c[3], w[3];
+        v3sub(w, p0, cb);
+        int nfix = 0, kf = -1;
+        for (int k = 0; k < 3; k++) {
+            c[k] = v3dot(w, B[k]);
+            if (RFABS(c[k]) >= hb[k] * (1 - (real)1e-6)) nfix++; else kf = k;
+        }
+        real wq[3];
+        v3sub(wq, qc, cc);
+        if (nfix == 2 && RFABS(v3dot(wq, a)) >= hl * (1 - (real)1e-6)) {      /* ... and the cylinder's point on a cap */
+            real base[3], x[3], q[3];
+            v3cpy(base, p0); v3axpy(base, -c[kf], B[kf]);
+            real t0 = -hb[kf], t1 = hb[kf], g0, g1;
+            v3cpy(x, base); v3axpy(x, t0, B[kf]); closest_on_cyl(cc, a, rad, hl, x, q); v3sub(w, x, q); g0 = v3dot(w, B[kf]);
+            v3cpy(x, base); v3axpy(x, t1, B[kf]); closest_on_cyl(cc, a, rad, hl, x, q); v3sub(w, x, q); g1 = v3dot(w, B[kf]);
+            real t = c[kf];
+            if (g0 < 0 && g1 > 0) {
+                for (int it = 0; it < 8; it++) {
+                    t = (t0 * g1 - t1 * g0) / (g1 - g0);
+                    v3cpy(x, base); v3axpy(x, t, B[kf]); closest_on_cyl(cc, a, rad, hl, x, q); v3sub(w, x, q);
+                    real g = v3dot(w, B[kf]);
+                    if (g > 0) { t1 = t; g1 = g; g0 *= (real)0.5; } else { t0 = t; g0 = g; g1 *= (real)0.5; }
+                }
+                v3cpy(x, base); v3axpy(x, t, B[kf]);
+                closest_on_cyl(cc, a, rad, hl, x, q);
+                v3sub(w, q, x);
+                real e0[3];
+                v3sub(e0, qc, p0);
+                if (v3dot(w, w) < v3dot(e0, e0)) { v3cpy(qc, q); closest_on_box(cb, B, hb, qc, p0); }
+            }
+        }
+    }
+}
+/* Two starts: the box's closest point to the cylinder's centre, and -- when a cap is within 8 degrees of parallel to a face
+ * of the box -- the point where an edge of that face crosses the rim (face_rim_crossing): from the first one the rounds
+ * crawl ACROSS the face towards that edge at 0.3 % per round.  The closer pair wins. */
 static void cyl_box_closest(const real* cc, const real* a, real rad, real hl, const real* cb, const real (*B)[3],
                             const real* hb, real* qc, real* p0)
 {
     closest_on_box(cb, B, hb, cc, p0);
-    for (int it = 0; it < 6; it++) {
-        closest_on_cyl(cc, a, rad, hl, p0, qc);
-        closest_on_box(cb, B, hb, qc, p0);
+    closest_rounds(cc, a, rad, hl, cb, B, hb, qc, p0);
+    int kf = 0;
+    real bf = RFABS(v3dot(B[0], a));
+    for (int k = 1; k < 3; k++) { real x = RFABS(v3dot(B[k], a)); if (x > bf) { bf = x; kf = k; } }
+    if (bf > (real)0.99 && bf < (real)0.9999995) {
+        real d[3], n[3], pc[3], fc[3], q[3], tq;
+        v3sub(d, cc, cb);
+        real sg = v3dot(d, a) < 0 ? (real)-1 : (real)1;           /* n = +-a from the box towards the cylinder */
+        v3set(n, sg * a[0], sg * a[1], sg * a[2]);
+        v3cpy(pc, cc); v3axpy(pc, -hl, n);
+        real nb = v3dot(n, B[kf]) > 0 ? (real)1 : (real)-1;
+        v3cpy(fc, cb); v3axpy(fc, nb * hb[kf], B[kf]);
+        int f1 = (kf + 1) % 3, f2 = (kf + 2) % 3;
+        if (face_rim_crossing(fc, B[f1], hb[f1], B[f2], hb[f2], pc, n, rad, n, (real)1, q, &tq)) {
+            real q2[3], e0[3], e1[3];
+            closest_rounds(cc, a, rad, hl, cb, B, hb, q2, q);
+            v3sub(e0, qc, p0); v3sub(e1, q2, q);
+            if (v3dot(e1, e1) < v3dot(e0, e0)) { v3cpy(qc, q2); v3cpy(p0, q); }
+        }
     }
 }
 static int reduce4(const real (*pts)[3], const real* sep, int m, int* sel)
@@ -1099,23 +1222,26 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             real pc[3];
             v3cpy(pc, cc); v3axpy(pc, sg * hl, a);
             {   /* a tilted cap touches with ONE rim point, the lowest along n: it leads the candidates (the four fixed
-                 * samples below would only find the contact several mm too late).  When the cap hangs over an edge of
-                 * the face the point is moved inside the face rectangle along the face, as the side case does; the
-                 * depth stays that of the rim point */
+                 * samples below would only find the contact several mm too late) -- when it lies over the face.  When the
+                 * cap hangs over an edge of the face the deepest point is where that edge crosses the rim */
                 real md[3];
                 for (int x = 0; x < 3; x++) md[x] = n[x] - can * a[x];
                 real ml = v3norm(md);
                 if (ml > (real)1e-3) {
                     real p[3], w[3];
                     v3cpy(p, pc); v3axpy(p, -rad / ml, md);
-                    v3sub(w, p, fp);
-                    real sd = v3dot(w, n);
                     v3sub(w, p, cb);
-                    real c1 = v3dot(w, B[j1]), c2 = v3dot(w, B[j2]);
-                    real k1 = c1 < -hb[j1] ? -hb[j1] : (c1 > hb[j1] ? hb[j1] : c1);
-                    real k2 = c2 < -hb[j2] ? -hb[j2] : (c2 > hb[j2] ? hb[j2] : c2);
-                    v3axpy(p, k1 - c1, B[j1]); v3axpy(p, k2 - c2, B[j2]);
-                    v3cpy(pts[m], p); sep[m] = sd; m++;
+                    if (RFABS(v3dot(w, B[j1])) <= hb[j1] && RFABS(v3dot(w, B[j2])) <= hb[j2]) {
+                        v3sub(w, p, fp);
+                        v3cpy(pts[m], p); sep[m] = v3dot(w, n); m++;
+                    } else {
+                        real fc[3], q[3], tq;
+                        real nb = v3dot(n, B[bk]) > 0 ? (real)1 : (real)-1;
+                        v3cpy(fc, cb); v3axpy(fc, nb * hb[bk], B[bk]);
+                        if (face_rim_crossing(fc, B[j1], hb[j1], B[j2], hb[j2], pc, a, rad, n, can, q, &tq)) {
+                            v3cpy(pts[m], q); v3axpy(pts[m], tq, n); sep[m] = tq; m++;
+                        }
+                    }
                 }
             }
             for (int c = 0; c < 4; c++) {              /* rim points inside the face rectangle */
@@ -1196,6 +1322,19 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             real rho2 = v3dot(w, w) - wa * wa;
             if (rho2 > rad * rad) continue;
             v3cpy(pts[m], q8[c]); v3axpy(pts[m], -wa, n); sep[m] = -wa; m++;
+        }
+        {   /* the box face that looks at the cap: where its edges cross the rim (face_rim_crossing) */
+            int kf = 0;
+            real bf = RFABS(v3dot(B[0], n));
+            for (int k = 1; k < 3; k++) { real x = RFABS(v3dot(B[k], n)); if (x > bf) { bf = x; kf = k; } }
+            int f1 = (kf + 1) % 3, f2 = (kf + 2) % 3;
+            real fc[3], q[3], tq;
+            real nb = v3dot(n, B[kf]) > 0 ? (real)1 : (real)-1;
+            v3cpy(fc, cb); v3axpy(fc, nb * hb[kf], B[kf]);
+            if (m < 8 && bf > (real)0.7 && bf < (real)0.9999995 &&
+                face_rim_crossing(fc, B[f1], hb[f1], B[f2], hb[f2], pc, n, rad, n, (real)1, q, &tq)) {
+                v3cpy(pts[m], q); v3axpy(pts[m], tq, n); sep[m] = tq; m++;
+            }
         }
         if (m == 0) {
             real q[3], w[3];
