@@ -228,6 +228,26 @@ def box_box(ca, Ra, ha, cb, Rb, hb, margin=0.002, f32=False):
     return out.reshape(4, 10)[:n]
 
 
+class FloorOracle(OracleEnv):
+    """The CHAOS FLOOR yardstick: the float64 oracle with its joint / block / door state rounded to float32 after every
+    substep (`state_f32_per_substep`, oracle/pmg_oracle.c) -- float64 arithmetic on a float32 state, the best any
+    implementation that keeps its state in float32 can do.  How far it strays from the plain float64 oracle, and how often
+    by more than 1e-3 (a contact made or missed one substep apart), does not depend on anybody's arithmetic: the bars of
+    the -m gpu contact tests are multiples of THAT, not of the float32 build of the oracle (a poor float32 code whose own
+    outliers are 10-100 x as many, profiles/r04_chaos_floor.txt)."""
+
+    def __init__(self, task, num_envs, **kw):
+        kw.pop('f32', None)
+        OracleEnv.__init__(self, task, num_envs, f32=False, **kw)
+
+    def step(self, actions):
+        set_prior('state_f32_per_substep', 1.0)        # process-wide switch: on for this call only
+        try:
+            return OracleEnv.step(self, actions)
+        finally:
+            set_prior('state_f32_per_substep', 0.0)
+
+
 def cyl_box(cc, Rc, rad, hl, cb, Rb, hb, margin=0.002, f32=False):
     lib = load(f32)
     a = [np.ascontiguousarray(x, np.float64) for x in (cc, Rc, cb, Rb, hb)]
