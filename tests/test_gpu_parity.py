@@ -215,7 +215,9 @@ def test_constructed_chest_contacts_match_oracle(built, task):
         a32, r32, _, _ = o32.step(a)
     err = np.abs(o['achieved_goal'] - a64['achieved_goal']).max(1)        # door joint + block positions
     spread = np.abs(a32['achieved_goal'] - a64['achieved_goal']).max(1)
-    _max_or_count('%s constructed, door + blocks' % task, err, spread)
+    # chest_pick_and_place: 2 of the 64 envs sit AT the bar (1.0e-3, 1.25e-3; chaos floor 0, the float32 oracle 3): the lid's
+    # handle between the closing fingers -- ABOVE_FLOOR of tests/test_gpu_tail_parity.py is the same effect in numbers
+    _max_or_count('%s constructed, door + blocks' % task, err, spread, extra=1 if task == 'chest_push' else 3)
     tip_err = np.abs(o['observation'][:, :3] - a64['observation'][:, :3]).max(1)
     _max_or_count('%s constructed, tip' % task, tip_err, np.abs(a32['observation'][:, :3] - a64['observation'][:, :3]).max(1))
     so = ora.get_state()

@@ -94,7 +94,8 @@ def test_teacher_forced_outliers_against_the_chaos_floor(built, task):
 
 
 # whole episodes: (p99 of the object-position error, envs beyond 1e-3, differing flags) where twice the chaos floor does not hold
-EPISODE_ABOVE_FLOOR = {}
+# chest_push-2: p99 1.3e-2 against the floor's 1.7e-3, 42 envs of 1024 beyond 1e-3 against 15 (round 4; the float32 oracle: 2.1e-2 / 50)
+EPISODE_ABOVE_FLOOR = {'chest_push': (2e-2, 60, 205)}
 
 
 @pytest.mark.parametrize('task', ['push', 'pick_and_place', 'block_stack', 'block_rearrange', 'chest_push'])
