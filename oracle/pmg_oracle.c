@@ -1180,9 +1180,30 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             cyl_box_closest(cc, a, rad, hl, cb, (const real (*)[3])B, hb, qc, p0);
             v3sub(L, qc, p0);
             real len = v3norm(L);
-            if (len < (real)1e-9) continue;
-            for (int x = 0; x < 3; x++) L[x] /= len;
-            v3cpy(q3, qc); v3cpy(L3, L); len3 = len;
+            if (len < (real)1e-9) {
+                /* PENETRATING shapes have no closest pair.  What this pass finds for a box edge that runs ALONG the cylinder
+                 * (|a . B_k| > 0.7: a finger's vertical edge against the puck's side) while the two are apart -- the radial
+                 * direction through that edge -- is then taken from the geometry: the box vertex nearest to the cylinder's
+                 * centre, seen across the axis.  Without it the least penetration was taken over the face normals alone: a
+                 * finger corner 0.15 mm inside the puck's side was reported 8.5 mm deep along the finger's face normal, and
+                 * the contact's error reduction launched the puck at 0.65 m/s (tools/strike_puck.py).  Treated as an
+                 * axis x edge direction (one lateral contact point). */
+                real bp = RFABS(v3dot(B[0], a));
+                for (int q = 1; q < 3; q++) { real x = RFABS(v3dot(B[q], a)); if (x > bp) bp = x; }
+                if (bp <= (real)0.7) continue;
+                real c[3], dm[3];
+                v3sub(dm, cb, cc);
+                v3cpy(c, dm);
+                for (int q = 0; q < 3; q++) v3axpy(c, v3dot(dm, B[q]) > 0 ? -hb[q] : hb[q], B[q]);
+                v3axpy(c, -v3dot(c, a), a);
+                real lc = v3norm(c);
+                if (lc < (real)1e-6) continue;
+                type = 2; k = 0;
+                for (int x = 0; x < 3; x++) L[x] = c[x] / lc;
+            } else {
+                for (int x = 0; x < 3; x++) L[x] /= len;
+                v3cpy(q3, qc); v3cpy(L3, L); len3 = len;
+            }
         }
         real t = v3dot(d, L), ca = v3dot(a, L);
         real rc = hl * RFABS(ca) + rad * RSQRT(1 - ca * ca > 0 ? 1 - ca * ca : 0);

@@ -72,8 +72,7 @@ __global__ void __launch_bounds__(128, PMG_WAVES_PER_EU) PMG_REACH_VGPRS pmg_k_s
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) PMG_REACH_VGPRS pmg_k_redo(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    if ((int)blockIdx.x >= redo[0]) return;
-    pmg::step_env<0, 8, false>(P, actions, redo[1 + blockIdx.x]);
+    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<0, 8, false>(P, actions, redo[1 + i]);
 }
 
 __global__ void __launch_bounds__(1024) pmg_k_plan(pmg::EnvParams P, const float* __restrict__ actions)
@@ -240,8 +239,7 @@ template <bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    if ((int)blockIdx.x >= redo[0]) return;
-    pmg::step_env<1, 24, CYL>(P, actions, redo[1 + blockIdx.x]);
+    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<1, 24, CYL>(P, actions, redo[1 + i]);
 }
 /* several free blocks (block_stack / block_rearrange): list 0 = envs whose gripper works on a block, with the full
  * 48-contact store; list 1 = the rest with a 30-contact store (20 KB of LDS instead of 29: 8 workgroups per CU instead
@@ -279,8 +277,7 @@ __global__ void __launch_bounds__(LIST == 0 && PMG_LIST_TWO_WAVES ? 128 : 64, PM
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_multi(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    if ((int)blockIdx.x >= redo[0]) return;
-    pmg::step_env<5, 48, false>(P, actions, redo[1 + blockIdx.x]);
+    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<5, 48, false>(P, actions, redo[1 + i]);
 }
 /* chest tasks: the same two-list split -- list 0 (gripper at the chest or at a block) keeps the full layout (48 contacts,
  * a stage slot per pair, 32 000 B = 5 workgroups per CU), list 1 runs ContactLds<6, 30> with ranked stage slots
@@ -289,9 +286,11 @@ template <int CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_chest(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    if ((int)blockIdx.x >= redo[0]) return;
-    pmg::step_env<6, 48, CYL>(P, actions, redo[1 + blockIdx.x]);
+    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<6, 48, CYL>(P, actions, redo[1 + i]);
 }
+/* the redo lists are short or empty (mispredictions, overflows of the small stores): 1024 workgroups walk them with a stride
+ * instead of one workgroup per env leaving on its first load -- dispatching 4096 empty workgroups is 5 us of a 0.94 ms step */
+static inline int redo_grid(int n_envs) { return n_envs < 1024 ? n_envs : 1024; }
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
                            hipEvent_t ev_fork, hipEvent_t ev_join)
 {
@@ -304,8 +303,8 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         (void)hipStreamWaitEvent(s, ev_join, 0);
-        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_redo_chest<2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
-        else hipLaunchKernelGGL((pmg_k_redo_chest<3>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_redo_chest<2>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_redo_chest<3>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         return hipGetLastError();
     }
     if (P.chest >= 0) {
@@ -323,7 +322,7 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         if (P.nb <= 4) hipLaunchKernelGGL((pmg_k_step_list<4, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<5, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
         (void)hipStreamWaitEvent(s, ev_join, 0);
-        hipLaunchKernelGGL(pmg_k_redo_multi, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        hipLaunchKernelGGL(pmg_k_redo_multi, dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         return hipGetLastError();
     }
     if (P.nb == 1 && packed) {
@@ -335,23 +334,24 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
             (void)hipEventRecord(ev_join, side);
             hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(OBJ4_THREADS), 0, s, P, d_actions);
             (void)hipStreamWaitEvent(s, ev_join, 0);
-            hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         } else {
             hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
             (void)hipEventRecord(ev_join, side);
             hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(OBJ4_THREADS), 0, s, P, d_actions);
             (void)hipStreamWaitEvent(s, ev_join, 0);
-            hipLaunchKernelGGL((pmg_k_redo_obj<false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_redo_obj<false>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         }
         return hipGetLastError();
     }
     if (P.nb == 0 && packed) {
         /* the one-wavefront kernel FIRST: when it is its turn (a contact-free step) its 1024 wavefronts are placed on an
          * empty machine, one per SIMD; behind the other kernel's draining empty workgroups they were not (0.82 ms) */
-        hipLaunchKernelGGL(pmg_k_step_reach, dim3(P.n_envs), dim3(64), 0, s, P, d_actions, packed == 2 ? 1 : 0);  /* n_prone + ceil(n_free / 4) <= N */
+        /* n_prone + ceil(n_free / 4) <= N workgroups; deferring (packed == 2) it runs on contact-free steps only: ceil(N / 4) */
+        hipLaunchKernelGGL(pmg_k_step_reach, dim3(packed == 2 ? (P.n_envs + 3) / 4 : P.n_envs), dim3(64), 0, s, P, d_actions, packed == 2 ? 1 : 0);
         if (packed == 2) hipLaunchKernelGGL(pmg_k_step_reach2, dim3(P.n_envs), dim3(128), 0, s, P, d_actions);   /* n_prone + ceil(n_free / 8) <= N */
         /* mispredictions are rare; surplus workgroups of the redo grid exit on their first instruction */
-        hipLaunchKernelGGL(pmg_k_redo, dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        hipLaunchKernelGGL(pmg_k_redo, dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
     } else if (P.nb == 0) hipLaunchKernelGGL((pmg_k_step<0, 8, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     else if (P.task == PMG_TASK_SLIDE) hipLaunchKernelGGL((pmg_k_step<1, 24, true>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
     else if (P.nb == 1) hipLaunchKernelGGL((pmg_k_step<1, 24, false>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
