@@ -1180,7 +1180,7 @@ static int cyl_box(const real* cc, const real* Rc, real rad, real hl, const real
             cyl_box_closest(cc, a, rad, hl, cb, (const real (*)[3])B, hb, qc, p0);
             v3sub(L, qc, p0);
             real len = v3norm(L);
-            if (len < (real)1e-9) {
+            if (len < (real)1e-6) {        /* (1 um: what float32 resolves of two coinciding points at 0.5 m) */
                 /* PENETRATING shapes have no closest pair.  What this pass finds for a box edge that runs ALONG the cylinder
                  * (|a . B_k| > 0.7: a finger's vertical edge against the puck's side) while the two are apart -- the radial
                  * direction through that edge -- is then taken from the geometry: the box vertex nearest to the cylinder's

@@ -413,6 +413,29 @@ def test_device_narrowphase_matches_oracle_on_random_pairs(emu_library, kind):
     assert checked > 130
 
 
+def test_device_cyl_box_corner_in_the_side_matches_oracle(emu_library):
+    """The product's cyl_box on a box corner touching / inside the cylinder's side (a finger's edge against the puck): the
+    planar corner-to-circle distance, as the oracle -- in float32 the coinciding closest points of penetrating shapes are
+    1e-8 apart, not 0, so the switch to the radial axis sits at 1 um in both."""
+    lib = C.CDLL(emu_library.path)
+    lib.pmge_probe_narrowphase.restype = C.c_int
+    I = np.eye(3, dtype=np.float32).ravel()
+    cc, ha, hb = np.float32([-0.495, 0.0979, 0.17]), np.float32([0.03, 0.03, 0.01]), np.float32([0.0125, 0.005, 0.04])
+    checked = 0
+    for yoff in (0.0157, 0.0257):
+        for gap in np.arange(0.042, 0.028, -0.001):
+            cb = np.float32([cc[0] + gap, cc[1] + yoff, 0.207])
+            out = np.zeros(40, np.float32)
+            n = lib.pmge_probe_narrowphase(1, _fp(cc), _fp(I), _fp(ha), _fp(cb), _fp(I), _fp(hb), C.c_float(0.002), _fp(out))
+            ref = O.cyl_box(cc.astype(float), I.astype(float), 0.03, 0.01, cb.astype(float), I.astype(float), hb.astype(float))
+            assert n == len(ref), (yoff, gap, n, len(ref))
+            if n:
+                got = out.reshape(4, 10)[:n]
+                assert abs(got[:, 9].min() - ref[:, 9].min()) < 2e-6 and np.abs(got[0, 6:9] - ref[0, 6:9]).max() < 1e-4, (yoff, gap, got[:, 9], ref[:, 9])
+                checked += 1
+    assert checked > 10
+
+
 def test_axis_aligned_partner_front_end_is_bit_identical(emu_library):
     """The reach kernel's narrowphase instantiation knows that box B (the table) is axis-aligned and leaves the sums with
     exact zeros out of the separating-axis front end: same contacts, same bits as the general routine on fingers in

@@ -384,3 +384,31 @@ def test_narrowphase_distance_agrees_with_closest_point_solver(built, shape, til
     assert len(errs) >= 55
     assert np.median(np.abs(errs)) < 1e-6                       # the typical pose: identical (to the solver's convergence)
     assert (np.abs(errs) > 1e-4).mean() <= frac_bar and np.abs(errs).max() <= worst_bar and missed <= miss_bar
+
+
+def test_box_corner_inside_the_cylinder_side_reports_the_true_penetration(built):
+    """A finger's vertical edge against the puck's side (box edge parallel to the cylinder axis), from 2 mm apart to 3 mm
+    deep: the distance must be the planar corner-to-circle one on both sides of contact.  Penetrating shapes have no
+    closest pair; round 3's axis set then fell back to the finger's face normal -- 8.5 mm for a true 0.15 mm -- and the
+    error reduction of that depth launched the puck at 0.65 m/s (tools/strike_puck.py)."""
+    I = np.eye(3).ravel()
+    cc, r, hl = np.array([-0.495, 0.0979, 0.17]), 0.03, 0.01
+    hb = np.array([0.0125, 0.005, 0.04])
+    checked = 0
+    for yoff in (0.0157, 0.0257, -0.0257):
+        for gap in np.arange(0.044, 0.028, -0.001):
+            cb = np.array([cc[0] + gap, cc[1] + yoff, 0.207])
+            dx, dy = max(abs(cb[0] - cc[0]) - hb[0], 0.0), max(abs(cb[1] - cc[1]) - hb[1], 0.0)
+            if dx == 0.0 or dy == 0.0:
+                continue                                   # the axis runs under the box's face: a face contact
+            true = np.hypot(dx, dy) - r
+            c = O.cyl_box(cc, I, r, hl, cb, I, hb)
+            if true > 0.002:
+                assert len(c) == 0
+                continue
+            assert len(c) >= 1 and abs(c[:, 9].min() - true) < 1e-6, (yoff, gap, true, c[:, 9])
+            n = c[0, 6:9]
+            want = np.array([cc[0] - (cb[0] - np.sign(cb[0] - cc[0]) * hb[0]), cc[1] - (cb[1] - np.sign(cb[1] - cc[1]) * hb[1]), 0.0])
+            assert np.abs(n - want / np.linalg.norm(want)).max() < 1e-6      # from the box's corner to the cylinder's axis
+            checked += 1
+    assert checked > 20
