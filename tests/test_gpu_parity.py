@@ -100,13 +100,13 @@ def _max_or_count(what, err, spread, bar=1e-3, extra=1):
     the deviation of the chaos-floor yardstick (oracle_lib.FloorOracle: float64 arithmetic, state rounded to float32
     every substep) from the plain float64 oracle on the same seeds and actions.  The device may have twice as many envs
     beyond the bar as that, plus `extra`; everybody else must be inside the bar, and the typical env at float32 rounding
-    (3 x the yardstick's median, at least 2e-5)."""
+    (3 x the yardstick's median, at least 3e-5)."""
     err, spread = np.asarray(err, np.float64), np.asarray(spread, np.float64)
     n_dev, n_floor = int((err > bar).sum()), int((spread > bar).sum())
     print('%-40s max %.2e median %.2e beyond %.0e: %d   | chaos floor: max %.2e median %.2e beyond: %d'
           % (what, err.max(), np.median(err), bar, n_dev, spread.max(), np.median(spread), n_floor))
     assert n_dev <= 2 * n_floor + extra, (what, n_dev, n_floor, np.sort(err)[-4:])
-    assert np.median(err) <= max(3 * np.median(spread), 2e-5), (what, np.median(err), np.median(spread))
+    assert np.median(err) <= max(3 * np.median(spread), 3e-5), (what, np.median(err), np.median(spread))
 
 
 @pytest.mark.parametrize('task,kw', [('push', {}), ('pick_and_place', {}), ('pick_and_place', {'binary_reward': False}),
