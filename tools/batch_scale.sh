@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: validation at scale (beyond what the -m gpu tier has time for) + phase timings of the final kernels.
 #   tools/batch_scale.sh [round-tag]
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/scale; rm -rf $out; mkdir -p $out
 # 1. whole-episode error percentiles, device and float32 oracle vs the float64 oracle, 2048 envs x 50 random steps
 for t in push slide pick_and_place block_stack block_rearrange chest_push chest_pick_and_place; do

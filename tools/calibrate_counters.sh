@@ -7,7 +7,7 @@
 # Also records the reward kernels under --kernel-trace (their duration by the profiler, not by host timers).
 #   tools/calibrate_counters.sh [round-tag]
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/calib; rm -rf $out; mkdir -p $out $root/gpurun_out/profiles
 cd /tmp && export TMPDIR=/tmp

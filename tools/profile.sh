@@ -5,7 +5,7 @@
 # 2. separate --pmc passes (never combined with traces): FETCH_SIZE, WRITE_SIZE, SQ instruction / wait / fp32-op counters
 # Summaries land in gpurun_out/prof_<task>/ ; tools/profile_summarise.py turns them into profiles/<tag>_<task><N>_*.
 set -u
-task=${1:-reach}; tag=${2:-r03}; n=${3:-4096}
+task=${1:-reach}; tag=${2:-r04}; n=${3:-4096}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$task
 rm -rf $out; mkdir -p $out

@@ -4,7 +4,7 @@
 # gpurun_out/evidence/ with the names used in profiles/; copy it over with `cp gpurun_out/evidence/* profiles/`.
 #   tools/refresh_evidence.sh [round-tag] [tasks...]
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $root
@@ -21,6 +21,10 @@ for t in $tasks; do
   cp gpurun_out/profiles/${tag}_${t}4096_* $out/ 2>/dev/null
   cp gpurun_out/profiles/${tag}_${t}4096_* profiles/ 2>/dev/null     # bench.py reads the committed counter passes
 done
+# 2b. BASELINE config C4: pick_and_place x 8192 envs (kernel stats + counter passes, so that its bench line carries measured traffic)
+bash tools/profile.sh pick_and_place $tag 8192 > /dev/null 2>&1
+cp gpurun_out/profiles/${tag}_pick_and_place8192_* $out/ 2>/dev/null
+cp gpurun_out/profiles/${tag}_pick_and_place8192_* profiles/ 2>/dev/null
 # 3. the bench lines (headline = the default command)
 python bench.py > $out/${tag}_bench_reach4096.json 2>/dev/null
 python bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench_reach4096_driver_command.json 2>/dev/null
