@@ -77,7 +77,7 @@ TEACHER = {
 # Where the device does NOT stay within twice the chaos floor: its gross steps there are as many as the float32 build of
 # the ORACLE has on the same states (217 vs 234, 493 vs 982, 119 vs 120; 23 vs 28, 9 vs 17) and 10-100 x the floor -- float32
 # ARITHMETIC inside the 100-substep chain, at degenerate contact geometries (the gripper base grazing the chest's edges, the
-# puck on its rim), not state noise; the mechanism is open.  Listed, not
+# puck on its rim), not state noise; the reference face of two nearly parallel box faces flips inside a band as wide as the arithmetic's rounding.  Listed, not
 # absorbed: (task, quantity) -> cap on the count of gross steps (measured x 1.4) out of N x T env-steps.
 # (chest_push: 217 / 493 / 119 with round 3's cylinder narrowphase, 354 / 736 / 51 with round 4's -- the counts move by a
 # factor of two from build to build on the SAME trajectory, which is what arithmetic-level sensitivity looks like: caps at

@@ -65,7 +65,7 @@ def test_teacher_forced_single_step_maximum(built, task):
 # (measured x 1.4; device / floor / float32 oracle of round 4: slide block 17 / 0.5 / 25; chest_push tip 30 / 1 / 36, q_arm
 # 55 / 7.5 / 74, door 13 / 0.5 / 20; chest_pick_and_place tip 59 / 1 / 68, q_arm 125 / 1.5 / 138, door 77 / 3.5 / 81) -- the
 # device has as many as the float32 build of the oracle: float32 arithmetic at degenerate contact geometry (the puck
-# on its rim, the gripper base on the chest's edges; mechanism open), tests/test_gpu_scripted.py ABOVE_FLOOR
+# on its rim, the gripper base on the chest's edges; the reference-face flip between nearly parallel faces), tests/test_gpu_scripted.py ABOVE_FLOOR
 ABOVE_FLOOR = {('slide', 'block_pos'): 35, ('chest_push', 'tip_pos'): 60, ('chest_push', 'q_arm'): 115, ('chest_push', 'door_q'): 30,
                ('chest_pick_and_place', 'tip_pos'): 120, ('chest_pick_and_place', 'q_arm'): 250, ('chest_pick_and_place', 'door_q'): 160}   # (twice the measurements)
 P99 = {('chest_pick_and_place', 'q_arm'): 1.2e-4}     # 0.24 % of its steps are gross: the p99 sits on their edge (8.3e-5)
