@@ -72,7 +72,8 @@ __global__ void __launch_bounds__(128, PMG_WAVES_PER_EU) PMG_REACH_VGPRS pmg_k_s
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) PMG_REACH_VGPRS pmg_k_redo(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<0, 8, false>(P, actions, redo[1 + i]);
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<0, 8, false>(P, actions, redo[1 + blockIdx.x]);
 }
 
 __global__ void __launch_bounds__(1024) pmg_k_plan(pmg::EnvParams P, const float* __restrict__ actions)
@@ -239,7 +240,8 @@ template <bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<1, 24, CYL>(P, actions, redo[1 + i]);
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<1, 24, CYL>(P, actions, redo[1 + blockIdx.x]);
 }
 /* several free blocks (block_stack / block_rearrange): list 0 = envs whose gripper works on a block, with the full
  * 48-contact store; list 1 = the rest with a 30-contact store (20 KB of LDS instead of 29: 8 workgroups per CU instead
@@ -277,7 +279,8 @@ __global__ void __launch_bounds__(LIST == 0 && PMG_LIST_TWO_WAVES ? 128 : 64, PM
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_multi(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<5, 48, false>(P, actions, redo[1 + i]);
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<5, 48, false>(P, actions, redo[1 + blockIdx.x]);
 }
 /* chest tasks: the same two-list split -- list 0 (gripper at the chest or at a block) keeps the full layout (48 contacts,
  * a stage slot per pair, 32 000 B = 5 workgroups per CU), list 1 runs ContactLds<6, 30> with ranked stage slots
@@ -286,11 +289,13 @@ template <int CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_chest(pmg::EnvParams P, const float* __restrict__ actions)
 {
     const int* redo = P.sched + 2 + 2 * P.n_envs;
-    for (int i = (int)blockIdx.x; i < redo[0]; i += (int)gridDim.x) pmg::step_env<6, 48, CYL>(P, actions, redo[1 + i]);
+    if ((int)blockIdx.x >= redo[0]) return;
+    pmg::step_env<6, 48, CYL>(P, actions, redo[1 + blockIdx.x]);
 }
-/* the redo lists are short or empty (mispredictions, overflows of the small stores): 1024 workgroups walk them with a stride
- * instead of one workgroup per env leaving on its first load -- dispatching 4096 empty workgroups is 5 us of a 0.94 ms step */
-static inline int redo_grid(int n_envs) { return n_envs < 1024 ? n_envs : 1024; }
+/* (a redo list walked with a stride by 1024 workgroups instead of one workgroup per env leaving on its first load would save the
+ * dispatch of 4096 empty workgroups, ~3 us -- but step_env inside that loop spills ~100 VGPRs to scratch, and as a noinline
+ * function it needs a 500-byte frame: measured, not kept) */
+static inline int redo_grid(int n_envs) { return n_envs; }
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
                            hipEvent_t ev_fork, hipEvent_t ev_join)
 {
