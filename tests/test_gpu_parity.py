@@ -40,6 +40,12 @@ def test_reach_rollout_matches_oracle(built, joint_control):
     OBS_TOL = 2e-4 if not joint_control else 1e-3
     STATE_TOL = 5e-4 if not joint_control else 5e-3     # the state rows hold velocities too (solver early exit: ~3e-4 m/s)
     env, ora = _pair('reach', N, joint_control=joint_control)
+    # joint control: the envs whose fingers scrape the table bifurcate (stick / slip) -- how many does the chaos floor lose
+    # (oracle_lib.FloorOracle: float64 arithmetic, the state rounded to float32 every substep)?  The device may lose twice as
+    # many + 1, at least JOINT_OUTLIERS
+    floor = oracle_lib.FloorOracle('reach', N, seed_base=0, seed_stride=1, threads=8, joint_control=True) if joint_control else None
+    if floor is not None:
+        floor.reset(), floor.reset()
     o, oo = env.reset(), ora.reset()
     assert np.array_equal(o['desired_goal'], oo['desired_goal'])
     assert np.abs(o['observation'] - oo['observation']).max() < 1e-5
@@ -51,6 +57,8 @@ def test_reach_rollout_matches_oracle(built, joint_control):
         a = rs.uniform(-1, 1, (N, A)).astype(np.float32)
         o, r, d, info = env.step(a)
         oo, ro, do, oko = ora.step(a)
+        if floor is not None:
+            floor.step(a)
         per_env = np.maximum(per_env, np.abs(o['observation'] - oo['observation']).max(1))
         worst = float(per_env.max()) if not joint_control else float(np.sort(per_env)[-1 - JOINT_OUTLIERS])
         assert np.array_equal(d, do)
@@ -61,7 +69,12 @@ def test_reach_rollout_matches_oracle(built, joint_control):
         assert np.array_equal(info['goal_achieved'][clear], oko[clear])
     assert worst < OBS_TOL, worst
     serr = np.abs(env.get_state() - ora.get_state()).max(1)
-    assert (serr.max() if not joint_control else np.sort(serr)[-1 - JOINT_OUTLIERS]) < STATE_TOL
+    allowed = 0
+    if joint_control:
+        ferr = np.abs(floor.get_state() - ora.get_state()).max(1)
+        allowed = max(JOINT_OUTLIERS, 2 * int((ferr > STATE_TOL).sum()) + 1)
+        print('joint control: envs beyond %.0e in the state rows: device %d, chaos floor %d' % (STATE_TOL, (serr > STATE_TOL).sum(), (ferr > STATE_TOL).sum()))
+    assert np.sort(serr)[-1 - allowed] < STATE_TOL
     assert np.median(per_env) < 2e-4
     assert d.all()
     env.close()
