@@ -196,6 +196,7 @@ __device__ __forceinline__ bool contact_prone(const EnvParams& P, const float* a
  * every (chunk, wave) tile in LDS, then each tile scatters at its exclusive prefix */
 constexpr int PLAN_THREADS = 1024, PLAN_MAX_TILES = 1024;
 constexpr int PLAN_SINGLE_MAX = 16384;   /* the single-workgroup plan serves batches up to here (<= PLAN_MAX_TILES * 64) */
+constexpr int PLAN_TWO_PASS_MIN = 4096;  /* ... and by default only below here: from four workgroups on the two-pass plan is the shorter one (pmg_launch_plan) */
 #ifndef PMG_FD_DIV
 #define PMG_FD_DIV 8
 #endif

@@ -204,12 +204,15 @@ __global__ void __launch_bounds__(256) pmg_k_reward(const float* __restrict__ ag
 
 hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipStream_t s)
 {
-    /* one workgroup plans a batch in one launch (13 us at 4096 envs, but its 1024 threads walk the batch in chunks: 0.9 ms
-     * at 65 536); beyond PLAN_SINGLE_MAX envs the two-pass plan over ceil(N / 1024) workgroups takes over: same lists
-     * (tests/test_emulated_kernels.py), every batch size keeps the fast paths */
-    static const int force_two_pass = getenv("PMG_PLAN_TWO_PASS") ? atoi(getenv("PMG_PLAN_TWO_PASS")) : 0;   /* (experiments) */
-    if (P.n_envs <= pmg::PLAN_SINGLE_MAX && !force_two_pass && P.nb == 0 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan_reach, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
-    else if (P.n_envs <= pmg::PLAN_SINGLE_MAX && !force_two_pass) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    /* One workgroup plans a small batch in one launch.  From 4096 envs on the two-pass plan over ceil(N / 1024) workgroups
+     * takes over (same lists, tests/test_emulated_kernels.py): every thread classifies ONE env, so the two launches together
+     * are shorter than the single workgroup's walk over the batch in chunks (13 us at 4096 envs -- reach + 0.7 %,
+     * pick_and_place x 8192 + 0.8 %, push + 0.4 % measured --, 32 us with several blocks, 0.9 ms at 65 536).
+     * PMG_PLAN_TWO_PASS=0 / 1 forces either (experiments; batches beyond PLAN_SINGLE_MAX always take two passes) */
+    static const int force_two_pass = getenv("PMG_PLAN_TWO_PASS") ? atoi(getenv("PMG_PLAN_TWO_PASS")) : -1;
+    const bool two_pass = P.n_envs > pmg::PLAN_SINGLE_MAX || (force_two_pass >= 0 ? force_two_pass != 0 : P.n_envs >= pmg::PLAN_TWO_PASS_MIN);
+    if (!two_pass && P.nb == 0 && !P.joint_control) hipLaunchKernelGGL(pmg_k_plan_reach, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
+    else if (!two_pass) hipLaunchKernelGGL(pmg_k_plan, dim3(1), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
     else {
         const int nwg = (P.n_envs + pmg::PLAN_THREADS - 1) / pmg::PLAN_THREADS;
         hipLaunchKernelGGL(pmg_k_plan_count, dim3(nwg), dim3(pmg::PLAN_THREADS), 0, s, P, d_actions);
