@@ -302,14 +302,29 @@ static inline int redo_grid(int n_envs) { return n_envs; }
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
                            hipEvent_t ev_fork, hipEvent_t ev_join)
 {
+    /* Which of the two concurrent launches is submitted first.  list0_first: the full-store list -- the step's long
+     * wavefronts -- goes to the main stream at once and the fast-path list follows on the side stream behind the fork event
+     * (a few us later), so the long chains are placed on an empty machine.  Submitted second they started behind the
+     * first ROUND of the fast-path list's workgroups (3800 one-env wavefronts on 2048 slots: 1.8 ms late on a 4 ms chain):
+     * block_stack-4 0.66 -> 0.79 M, block_rearrange-4 0.54 -> 0.70 M, chest_pick_and_place-4 0.45 -> 0.57 M, chest_push-4
+     * 0.40 -> 0.42 M.  With ONE object the packed launch is the pole itself and stays first (push 1.63 -> 1.48 M otherwise) --
+     * until its workgroups alone fill the machine: five of them (31.8 KB of LDS each) hold a compute unit's LDS, so beyond
+     * 5 x CUs packed workgroups (wave_budget = 6 x CUs; 5120 envs) the one-env list waited for the first round of the packed
+     * launch to drain: pick_and_place x 8192 2.64 -> 2.84 M, x 6144 1.99 -> 2.13 M, push x 6144 1.74 -> 1.94 M (push / slide
+     * x 8192 and pick_and_place x 16 384: neutral).
+     * PMG_LIST0_FIRST=0 / 1 forces either order for every task (experiments) */
+    static const int force_first = getenv("PMG_LIST0_FIRST") ? atoi(getenv("PMG_LIST0_FIRST")) : -1;
+    const bool list0_first = force_first >= 0 ? force_first != 0 : (P.nb > 1 || P.chest >= 0 || (P.n_envs + 3) / 4 > P.wave_budget * 5 / 6);
     if (P.chest >= 0 && packed) {
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
-        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
-        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
-        (void)hipEventRecord(ev_join, side);
-        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
-        else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
+        if (!list0_first) (void)hipEventRecord(ev_join, side);
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
+        if (list0_first) (void)hipEventRecord(ev_join, side);
         (void)hipStreamWaitEvent(s, ev_join, 0);
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_redo_chest<2>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_redo_chest<3>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
@@ -324,11 +339,13 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
     if (P.nb > 1 && packed) {
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
-        hipLaunchKernelGGL((pmg_k_step_list<5, 48, 0>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
-        (void)hipEventRecord(ev_join, side);
+        hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
+        hipLaunchKernelGGL((pmg_k_step_list<5, 48, 0>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
+        if (!list0_first) (void)hipEventRecord(ev_join, side);
         /* up to four blocks: 24 candidate pairs instead of 32 keep the narrowphase workspace under the row store (20 KB) */
-        if (P.nb <= 4) hipLaunchKernelGGL((pmg_k_step_list<4, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
-        else hipLaunchKernelGGL((pmg_k_step_list<5, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s, P, d_actions);
+        if (P.nb <= 4) hipLaunchKernelGGL((pmg_k_step_list<4, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<5, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
+        if (list0_first) (void)hipEventRecord(ev_join, side);
         (void)hipStreamWaitEvent(s, ev_join, 0);
         hipLaunchKernelGGL(pmg_k_redo_multi, dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         return hipGetLastError();
@@ -337,16 +354,19 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         (void)hipEventRecord(ev_fork, s);
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         const int groups = (P.n_envs + 3) / 4;
+        hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
         if (P.task == PMG_TASK_SLIDE) {
-            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
-            (void)hipEventRecord(ev_join, side);
-            hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(OBJ4_THREADS), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
+            if (!list0_first) (void)hipEventRecord(ev_join, side);
+            hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(OBJ4_THREADS), 0, s1, P, d_actions);
+            if (list0_first) (void)hipEventRecord(ev_join, side);
             (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         } else {
-            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, side, P, d_actions);
-            (void)hipEventRecord(ev_join, side);
-            hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(OBJ4_THREADS), 0, s, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
+            if (!list0_first) (void)hipEventRecord(ev_join, side);
+            hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(OBJ4_THREADS), 0, s1, P, d_actions);
+            if (list0_first) (void)hipEventRecord(ev_join, side);
             (void)hipStreamWaitEvent(s, ev_join, 0);
             hipLaunchKernelGGL((pmg_k_redo_obj<false>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         }
