@@ -366,11 +366,20 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         if (const char* fd = getenv("PMG_FD_DIV")) e->P.fd_div = atoi(fd);
         if (const char* wb = getenv("PMG_WAVE_BUDGET")) e->P.wave_budget = atoi(wb);
         e->P.env_cycles = nullptr;
-        if (const char* ec = getenv("PMG_ENV_CYCLES")) {
-            if (atoi(ec) != 0) {
-                CREATE_TRY(hipMalloc((void**)&e->P.env_cycles, 2 * N * sizeof(int)));
-                CREATE_TRY(hipMemset(e->P.env_cycles, 0, 2 * N * sizeof(int)));
-            }
+        /* Longest first on the fast-path list of the many-body tasks (4096 one-env wavefronts on 2048 slots run in two
+         * rounds: a long wavefront that starts in the second one is the tail of the step).  The predictor is the env's own
+         * wavefront time in the PREVIOUS step (cycles / 64, kept per env: 8 bytes); envs beyond the threshold lead the list
+         * (plan_class).  Thresholds by measurement (PMG_LPT_CYCLES sweep 0 / 60 / 70 / 85 / 100 k): chest_push-4 0.42 -> 0.46 M
+         * and chest_pick_and_place-4 0.57 -> 0.58 M at 85 k / 70 k, block_stack-4 0.79 -> 0.80 M at 60 k; block_rearrange
+         * loses (0.70 -> 0.61 M: there the fingers-down grouping it replaces IS the better order) and keeps it off.
+         * Results do not depend on the order of a launch list, only the schedule does */
+        e->P.lpt_thresh = dims.num_envs < 4096 ? 0 : (e->cfg.task == PMG_TASK_CHEST_PUSH ? 85000 : (e->cfg.task == PMG_TASK_CHEST_PICK_AND_PLACE ? 70000 :
+                          (e->cfg.task == PMG_TASK_BLOCK_STACK ? 60000 : 0)));
+        if (const char* lt = getenv("PMG_LPT_CYCLES")) e->P.lpt_thresh = atoi(lt);
+        const char* ec = getenv("PMG_ENV_CYCLES");
+        if ((ec && atoi(ec) != 0) || (e->P.lpt_thresh > 0 && e->nb > 1)) {
+            CREATE_TRY(hipMalloc((void**)&e->P.env_cycles, 2 * N * sizeof(int)));
+            CREATE_TRY(hipMemset(e->P.env_cycles, 0, 2 * N * sizeof(int)));
         }
         if (const char* pr = getenv("PMG_LIST0_PRIO")) e->P.list0_prio = atoi(pr);
     }

@@ -46,6 +46,7 @@ struct EnvParams {
                         lists, [2 + 2N] the redo count and behind it the redo list of the fast paths (pmg_packed.h); then
                         [3 + 3N ..) the per-workgroup class counts of the two-pass plan (3 per 1024 envs) and one last word:
                         did the plan promote the fingers-down class to list 0 (plan_promoted()) */
+    int lpt_thresh;  /* > 0 (and env_cycles kept): several blocks, fast-path list ordered longest-first -- envs whose wavefront took more than this many cycles / 64 in the PREVIOUS step lead the list (plan_class) */
     int* env_cycles; /* diagnostics (NULL unless PMG_ENV_CYCLES=1 at creation): [N, 2] shader cycles / 64 the env's wavefront spent
                         in its last step, and the largest contact count any of its substeps saw */
 #ifdef PMG_PROFILE
@@ -207,6 +208,7 @@ __device__ __forceinline__ int plan_class(const EnvParams& P, const float* actio
 {
     if (contact_prone(P, actions, env, in)) return 0;
     if (P.nb == 0) return 1;
+    if (P.nb > 1 && P.lpt_thresh > 0 && P.env_cycles) return P.env_cycles[2 * env] > P.lpt_thresh ? 1 : 2;
     float z = in.ee[2];
     float zn = fminf(fmaxf(z + in.a[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
     return fminf(z, zn) < P.ee_lo[2] + 0.012f ? 1 : 2;

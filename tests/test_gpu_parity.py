@@ -637,6 +637,39 @@ def test_plan_schedule_at_every_batch_size(built, N):
     env.close()
 
 
+@pytest.mark.parametrize('task', ['block_stack', 'chest_push'])
+def test_longest_first_order_of_the_fast_path_list_changes_the_schedule_only(built, task, monkeypatch):
+    """From 4096 envs on the plan of the many-body tasks orders the fast-path list by the envs' wavefront time in the previous
+    step (pmg_create: lpt_thresh).  The order of a launch list is no input of any env's arithmetic: with the
+    rule off (PMG_LPT_CYCLES=0) the same seeds and actions give the same states, bit for bit; with it on the list is a
+    permutation of the same envs whose head are the envs that were slow in the step before."""
+    N, T = 4096, 6
+    acts = np.random.RandomState(2).uniform(-1, 1, (T, N, 4)).astype(np.float32)
+    def run(lpt):
+        if lpt is None: monkeypatch.delenv('PMG_LPT_CYCLES', raising=False)
+        else: monkeypatch.setenv('PMG_LPT_CYCLES', lpt)
+        env = pmg.make_env(task=task, num_envs=N, seed=7, seed_stride=1, num_block=4)
+        env.reset()
+        for t in range(T - 1):
+            env.step(acts[t])
+        cyc = env.handle.env_cycles()[:, 0].astype(np.int64) if lpt is None else None
+        env.step(acts[T - 1])
+        out = env.get_state().copy(), env.handle.schedule(), cyc
+        env.close()
+        return out
+    s_off, sch_off, _ = run('0')
+    s_on, sch_on, cyc = run(None)
+    assert np.array_equal(s_on.view(np.uint32), s_off.view(np.uint32))
+    assert np.array_equal(np.sort(sch_on['free']), np.sort(sch_off['free'])) and np.array_equal(sch_on['prone'], sch_off['prone'])
+    assert len(sch_on['redo']) == len(sch_off['redo'])
+    thr = 60000 if task == 'block_stack' else 85000
+    slow = cyc[sch_on['free']] > thr
+    k = int(slow.sum())
+    assert 0 < k < len(slow)
+    assert slow[:k].all() and not slow[k:].any()                      # the slow envs of the previous step lead the list ...
+    assert not np.array_equal(sch_on['free'], sch_off['free'])       # ... which the default order does not do
+
+
 @pytest.mark.parametrize('task,kw', [('reach', {}), ('reach', {'binary_reward': False}), ('push', {}), ('slide', {}),
                                      ('pick_and_place', {'binary_reward': False}), ('block_stack', {'num_block': 4}),
                                      ('block_rearrange', {'num_block': 3})])
