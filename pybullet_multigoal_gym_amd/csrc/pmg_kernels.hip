@@ -259,8 +259,12 @@ constexpr int LIST0_THREADS = PMG_LIST_TWO_WAVES ? 128 : 64;
 #ifndef PMG_LIST_TWO_WAVES
 #define PMG_LIST_TWO_WAVES 1
 #endif
+/* ... except on the lid task (chest_pick_and_place, CYL == 3): a quarter of its batch is on list 0, the step is bound by the
+ * wavefront slots, not by one chain, and the helper wavefronts cost more slots than they shorten chains (0.580 -> 0.609 M
+ * without them; chest_push neutral, the block tasks lose 1 %: they keep theirs) */
+constexpr bool list_two_waves(int list, int cyl) { return list == 0 && PMG_LIST_TWO_WAVES != 0 && cyl != 3; }
 template <int NB, int MAXC, int LIST, int CYL = 0>
-__global__ void __launch_bounds__(LIST == 0 && PMG_LIST_TWO_WAVES ? 128 : 64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(list_two_waves(LIST, CYL) ? 128 : 64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmg::ContactLds<NB, MAXC> L;
     __shared__ pmg::LaneTabStore lcs;
@@ -272,7 +276,7 @@ __global__ void __launch_bounds__(LIST == 0 && PMG_LIST_TWO_WAVES ? 128 : 64, PM
      * with it and do not promote); PMG_LIST0_PRIO overrides (tools/prio_exp.sh) */
     if (LIST == 0) wv::set_priority(P.list0_prio >= 0 ? P.list0_prio : ((NB > 1 || *pmg::plan_promoted(P)) ? 1 : 0));
     const int env = P.sched[2 + LIST * P.n_envs + b];
-    const bool ok = pmg::step_env_core<NB, MAXC, CYL, LIST == 0 && PMG_LIST_TWO_WAVES>(P, actions, env, L, lcs, true);
+    const bool ok = pmg::step_env_core<NB, MAXC, CYL, list_two_waves(LIST, CYL)>(P, actions, env, L, lcs, true);
     if (!ok && threadIdx.x == 0) {
         int* redo = P.sched + 2 + 2 * P.n_envs;
         int slot = atomicAdd(redo, 1);
@@ -320,7 +324,7 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         (void)hipStreamWaitEvent(side, ev_fork, 0);
         hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
-        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(list_two_waves(0, 3) ? 128 : 64), 0, s0, P, d_actions);
         if (!list0_first) (void)hipEventRecord(ev_join, side);
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
