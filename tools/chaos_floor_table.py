@@ -3,7 +3,7 @@
 float32 ulp and rounded to float32 after every substep, tools/teacher_forced.py) and next to the float32 build of the oracle,
 per task, under the scripted task-solving policies and under the random policy.  One JSON line per (task, policy) and a
 table; profiles/r04_chaos_floor.{jsonl,txt} are this script's output.
-    tools/chaos_floor_table.py [scripted|random|all] > gpurun_out/chaos_floor.jsonl"""
+    tools/chaos_floor_table.py [scripted|random|all] [nof32] > gpurun_out/chaos_floor.jsonl   (nof32: without the float32-oracle column)"""
 import json
 import os
 import sys
@@ -27,12 +27,13 @@ def one(task, kw, N, T, policy_name):
     mk = (lambda: SP.make_policy(task, N, **pkw)) if policy_name == 'scripted' else (lambda: None)
     kw = dict(kw, max_episode_steps=T) if policy_name == 'scripted' else dict(kw)
     dev = TF.run(task, N, T, kw, device=True, threads=th, policy=mk(), perturb=2)
-    f32 = TF.run(task, N, T, kw, device=False, threads=th, policy=mk())
+    f32 = TF.run(task, N, T, kw, device=False, threads=th, policy=mk()) if 'nof32' not in sys.argv[2:] else None
     row = {'task': task, 'policy': policy_name, 'N': N, 'T': T, 'kw': kw, 'quantities': {}}
     for q in QUANT:
         if q not in dev['stats']:
             continue
-        d, f, c = dev['stats'][q], f32['stats'][q], dev['chaos'][q]
+        d, c = dev['stats'][q], dev['chaos'][q]
+        f = f32['stats'][q] if f32 is not None else {'n_gt_1e-3': -1, 'p99': float('nan')}
         row['quantities'][q] = {'env_steps': d['n'], 'device_gt_1e-3': d['n_gt_1e-3'], 'device_off_floor': c['off_floor'], 'floor_gt_1e-3': c['floor_per_perturbed_oracle'],
                                 'f32_oracle_gt_1e-3': f['n_gt_1e-3'], 'device_p99': d['p99'], 'floor_p99': c['perturbed_p99'], 'f32_oracle_p99': f['p99'],
                                 'device_max': d['max'], 'device_p50': d['p50']}
