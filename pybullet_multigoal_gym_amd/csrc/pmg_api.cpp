@@ -362,7 +362,9 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         if (const char* nr = getenv("PMG_NEAR_R")) e->P.near_r = (float)atof(nr);   /* (tuning experiments) */
         if (const char* cr = getenv("PMG_CHEST_REACH")) e->P.chest_reach = (float)atof(cr);
         e->P.list0_prio = -1;
-        e->P.fd_div = PMG_FD_DIV;
+        /* fingers-down class of the one-object tasks: to the one-env list for pick_and_place, packed for push / slide -- by task,
+         * never by batch statistics (results must not depend on how a job is sharded; EnvParams::fd_div) */
+        e->P.fd_div = e->cfg.task == PMG_TASK_PICK_AND_PLACE ? -1 : 0;
         if (const char* fd = getenv("PMG_FD_DIV")) e->P.fd_div = atoi(fd);
         if (const char* wb = getenv("PMG_WAVE_BUDGET")) e->P.wave_budget = atoi(wb);
         e->P.env_cycles = nullptr;

@@ -27,7 +27,10 @@ struct EnvParams {
     float chest_reach;      /* plan: how far in front of the chest's front face a tip target counts as "at the chest" */
     float near_r;           /* plan: a tip target within this distance of a free object sends the env to the full-store list */
     int wave_budget;        /* 1.5 wavefronts per SIMD of THIS device (6 x CUs: 1536 on an MI355X): pmg_k_plan's promotion rule */
-    int fd_div;             /* plan: the fingers-down class moves to list 0 while it is under 1 / fd_div of the batch (0: never) */
+    int fd_div;             /* plan: the fingers-down class of a one-object task goes to list 0: -1 always (pick_and_place: the default), 0 never (push,
+                               slide) -- a rule of the TASK, so that an env's kernel, and with it the float32 order of its sums, does not depend on
+                               the batch it is in; > 0 (experiments, PMG_FD_DIV): while the class is under 1 / fd_div of the batch and the step fits
+                               the wavefront budget, round 2-4's rule */
     int list0_prio;         /* s_setprio level of the full-store (list 0) wavefronts; -1: when they are the long pole of the step (pmg_k_step_list) */
     float thr;
     float ee_lo[3], ee_hi[3];
@@ -287,11 +290,12 @@ __device__ __forceinline__ void plan_all(const EnvParams& P, const float* action
     /* one free object, fingers down at the table (class 1: 8 more contacts = 24 more rows per sweep): such an env holds
      * its packed wavefront back for the whole step, alone on a wavefront it solves them in row space.  Worth a wavefront
      * each only while they are few (pick_and_place: +12 %; push / slide, where a fifth of the batch is down there at
-     * any time: -24 %), so the whole class moves to the first list, behind class 0, when it is under 1 / PMG_FD_DIV of
-     * the batch AND the step then still fits 1.5 wavefronts per SIMD (1024 SIMDs; at 8192 envs the packed wavefronts
-     * alone are two per SIMD and the extra one-env wavefronts cost more than they save: 1.74 -> 1.65 M) */
-    const bool promote = P.fd_div > 0 && P.nb == 1 && !P.joint_control && (long long)n1 * P.fd_div <= P.n_envs &&
-                         n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget;
+     * any time: -24 %), so pick_and_place moves the whole class to the first list, behind class 0, and push / slide do not.
+     * Rounds 2-4 decided it per step from batch-wide counts (under 1 / PMG_FD_DIV of the batch AND the step within 1.5
+     * wavefronts per SIMD): the two kernels sum in different float32 orders, so an env's trajectory depended on the batch it
+     * was in -- a run on 8 GPUs was not the run on 1 GPU.  Round 5: a rule of the task (EnvParams::fd_div) */
+    const bool promote = P.nb == 1 && !P.joint_control &&
+                         (P.fd_div < 0 || (P.fd_div > 0 && (long long)n1 * P.fd_div <= P.n_envs && n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget));
     for (int c = 0; c < chunks; c++) {
         int tile = c * waves + wave;
         int env = c * PLAN_THREADS + tid;
@@ -356,8 +360,8 @@ __device__ __forceinline__ void plan_scatter(const EnvParams& P, const float* ac
     if (lane == 0) { wcnt[0][wave] = __popcll(m0); wcnt[1][wave] = __popcll(m1); wcnt[2][wave] = __popcll(m2); }
     __syncthreads();
     const int n0all = tot[0], n1 = tot[1], n2all = tot[2];
-    const bool promote = P.fd_div > 0 && P.nb == 1 && !P.joint_control && (long long)n1 * P.fd_div <= P.n_envs &&
-                         n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget;
+    const bool promote = P.nb == 1 && !P.joint_control &&
+                         (P.fd_div < 0 || (P.fd_div > 0 && (long long)n1 * P.fd_div <= P.n_envs && n0all + n1 + ((n2all + 3) >> 2) <= P.wave_budget));
     int b0 = base[0], b1 = base[1], b2 = base[2];
     for (int w = 0; w < wave && w < waves; w++) { b0 += wcnt[0][w]; b1 += wcnt[1][w]; b2 += wcnt[2][w]; }
     if (cls == 0) P.sched[2 + b0 + __popcll(m0 & below)] = env;

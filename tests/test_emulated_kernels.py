@@ -543,3 +543,12 @@ def test_two_pass_plan_writes_the_same_lists_as_the_single_workgroup_plan(built,
     assert np.array_equal(a[2:2 + n0], b[2:2 + n0]) and np.array_equal(a[2 + N:2 + N + n1], b[2 + N:2 + N + n1])
     assert a[2 + 2 * N] == 0 and b[2 + 2 * N] == 0
     assert sorted(np.concatenate([b[2:2 + n0], b[2 + N:2 + N + n1]]).tolist()) == list(range(N))    # a partition of the batch
+
+
+@pytest.mark.parametrize('task', ['push', 'pick_and_place', 'slide'])
+def test_emulated_sharded_batch_is_bit_identical_to_the_unsharded_batch(emu_library, task):
+    """The product's kernels on the emulator: 24 envs in one batch against 3 shards of 8, half of the batch with its fingers
+    driven onto the table (the class whose kernel depended on batch-wide counts until round 5) -- outputs and state rows EQUAL
+    (tests/test_gpu_parity.py runs the same at 512 / 2 and 4096 / 8 on the device)."""
+    from test_gpu_parity import _sharded_equals_unsharded
+    _sharded_equals_unsharded(emu_library, task, 24, 3, 4)
