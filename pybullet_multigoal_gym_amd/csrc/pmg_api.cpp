@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/pmg.h"
@@ -418,6 +419,16 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
         CREATE_TRY(hipMemset(e->P.out, 0, N * dims.packed_dim * sizeof(float)));
     }
     if (upload_seeds(e) != PMG_OK) return bail(PMG_E_DEVICE);
+    {   /* the tuning / experiment switches this library reads from the environment change its schedule (never its results' meaning):
+         * a stray one in a user's shell -- PMG_PACKED=0 halves the throughput -- must not go unnoticed: ONE line on stderr per handle */
+        static const char* const kSwitches[] = {"PMG_PACKED", "PMG_REACH_TWO_WAVES", "PMG_NEAR_R", "PMG_CHEST_REACH", "PMG_FD_DIV", "PMG_WAVE_BUDGET",
+                                                "PMG_LPT_CYCLES", "PMG_ENV_CYCLES", "PMG_LIST0_PRIO", "PMG_LIST0_FIRST", "PMG_PLAN_TWO_PASS",
+                                                "PMG_REWARD_GENERIC"};
+        std::string active;
+        for (const char* name : kSwitches)
+            if (const char* v = getenv(name)) { active += active.empty() ? "" : " "; active += name; active += "="; active += v; }
+        if (!active.empty()) fprintf(stderr, "[libpmg_hip] environment overrides active for this handle: %s\n", active.c_str());
+    }
     *out = e;
     return PMG_OK;
 }

@@ -303,6 +303,10 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_chest(pmg::En
  * dispatch of 4096 empty workgroups, ~3 us -- but step_env inside that loop spills ~100 VGPRs to scratch, and as a noinline
  * function it needs a 500-byte frame: measured, not kept) */
 static inline int redo_grid(int n_envs) { return n_envs; }
+/* every runtime call of the fork / join between the step's two concurrent launches is checked: a failed event record or stream
+ * wait would silently serialise the two lists, or let the redo pass race them -- the error goes back to the caller
+ * (pmg_step*: PMG_ERR_HIP + pmg_last_error) */
+#define PMG_FJ(call) do { hipError_t fj_e_ = (call); if (fj_e_ != hipSuccess) return fj_e_; } while (0)
 hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipStream_t s, int packed, hipStream_t side,
                            hipEvent_t ev_fork, hipEvent_t ev_join)
 {
@@ -320,16 +324,16 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
     static const int force_first = getenv("PMG_LIST0_FIRST") ? atoi(getenv("PMG_LIST0_FIRST")) : -1;
     const bool list0_first = force_first >= 0 ? force_first != 0 : (P.nb > 1 || P.chest >= 0 || (P.n_envs + 3) / 4 > P.wave_budget * 5 / 6);
     if (P.chest >= 0 && packed) {
-        (void)hipEventRecord(ev_fork, s);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        PMG_FJ(hipEventRecord(ev_fork, s));
+        PMG_FJ(hipStreamWaitEvent(side, ev_fork, 0));
         hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(list_two_waves(0, 3) ? 128 : 64), 0, s0, P, d_actions);
-        if (!list0_first) (void)hipEventRecord(ev_join, side);
+        if (!list0_first) PMG_FJ(hipEventRecord(ev_join, side));
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
-        if (list0_first) (void)hipEventRecord(ev_join, side);
-        (void)hipStreamWaitEvent(s, ev_join, 0);
+        if (list0_first) PMG_FJ(hipEventRecord(ev_join, side));
+        PMG_FJ(hipStreamWaitEvent(s, ev_join, 0));
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_redo_chest<2>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_redo_chest<3>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         return hipGetLastError();
@@ -341,37 +345,37 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         return hipGetLastError();
     }
     if (P.nb > 1 && packed) {
-        (void)hipEventRecord(ev_fork, s);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        PMG_FJ(hipEventRecord(ev_fork, s));
+        PMG_FJ(hipStreamWaitEvent(side, ev_fork, 0));
         hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
         hipLaunchKernelGGL((pmg_k_step_list<5, 48, 0>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
-        if (!list0_first) (void)hipEventRecord(ev_join, side);
+        if (!list0_first) PMG_FJ(hipEventRecord(ev_join, side));
         /* up to four blocks: 24 candidate pairs instead of 32 keep the narrowphase workspace under the row store (20 KB) */
         if (P.nb <= 4) hipLaunchKernelGGL((pmg_k_step_list<4, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<5, MULTI_SMALL_MAXC, 1>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
-        if (list0_first) (void)hipEventRecord(ev_join, side);
-        (void)hipStreamWaitEvent(s, ev_join, 0);
+        if (list0_first) PMG_FJ(hipEventRecord(ev_join, side));
+        PMG_FJ(hipStreamWaitEvent(s, ev_join, 0));
         hipLaunchKernelGGL(pmg_k_redo_multi, dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         return hipGetLastError();
     }
     if (P.nb == 1 && packed) {
-        (void)hipEventRecord(ev_fork, s);
-        (void)hipStreamWaitEvent(side, ev_fork, 0);
+        PMG_FJ(hipEventRecord(ev_fork, s));
+        PMG_FJ(hipStreamWaitEvent(side, ev_fork, 0));
         const int groups = (P.n_envs + 3) / 4;
         hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
         if (P.task == PMG_TASK_SLIDE) {
             hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
-            if (!list0_first) (void)hipEventRecord(ev_join, side);
+            if (!list0_first) PMG_FJ(hipEventRecord(ev_join, side));
             hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(OBJ4_THREADS), 0, s1, P, d_actions);
-            if (list0_first) (void)hipEventRecord(ev_join, side);
-            (void)hipStreamWaitEvent(s, ev_join, 0);
+            if (list0_first) PMG_FJ(hipEventRecord(ev_join, side));
+            PMG_FJ(hipStreamWaitEvent(s, ev_join, 0));
             hipLaunchKernelGGL((pmg_k_redo_obj<true>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         } else {
             hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, false>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
-            if (!list0_first) (void)hipEventRecord(ev_join, side);
+            if (!list0_first) PMG_FJ(hipEventRecord(ev_join, side));
             hipLaunchKernelGGL((pmg_k_step_obj4<false>), dim3(groups), dim3(OBJ4_THREADS), 0, s1, P, d_actions);
-            if (list0_first) (void)hipEventRecord(ev_join, side);
-            (void)hipStreamWaitEvent(s, ev_join, 0);
+            if (list0_first) PMG_FJ(hipEventRecord(ev_join, side));
+            PMG_FJ(hipStreamWaitEvent(s, ev_join, 0));
             hipLaunchKernelGGL((pmg_k_redo_obj<false>), dim3(redo_grid(P.n_envs)), dim3(64), 0, s, P, d_actions);
         }
         return hipGetLastError();

@@ -169,18 +169,43 @@ def _is_loopback(addr):
     return addr in ('localhost', '::1') or addr.startswith('127.')
 
 
+def _is_local_address(addr):
+    """True when `addr` names THIS machine: a loopback name / address, or a host name / address that resolves to one of this
+    host's own interfaces (a launcher that exports the node's hostname or FQDN as MASTER_ADDR for a single-node job:
+    `torchrun --standalone`, SLURM wrappers).  An address is taken for one of ours when a socket can be bound to it."""
+    if _is_loopback(addr):
+        return True
+    try:
+        infos = socket.getaddrinfo(addr, None, proto=socket.IPPROTO_TCP)
+    except OSError:
+        return False
+    for fam, _, _, _, sa in infos:
+        ip = sa[0]
+        if ip.startswith('127.') or ip == '::1':
+            return True
+        try:
+            with socket.socket(fam, socket.SOCK_DGRAM) as probe:
+                probe.bind((ip, 0))
+            return True
+        except OSError:
+            continue
+    return False
+
+
 def job_token(addr='127.0.0.1'):
     """Token the hello of every rank carries.  With PMG_RDV_TOKEN set by the launcher it is a shared secret.  Without it the
     token is derived from the launcher's run id, master address / port and world size -- values anyone who can reach the
     port can guess -- so it only rejects STALE or ACCIDENTAL peers (another job, a port scanner), it does not authenticate.
-    That is acceptable on a loopback rendezvous (one node, the only case bench.py launches); on any other bind address
-    PMG_RDV_TOKEN is REQUIRED and its absence is an error."""
+    That is acceptable for a single-node job -- the rendezvous address is this machine: loopback, or the node's own host
+    name / interface address (_is_local_address) -- which is every case bench.py launches; when the master address is
+    ANOTHER machine (multi-node) PMG_RDV_TOKEN is REQUIRED and its absence is an error."""
     import hashlib
     tok = os.environ.get('PMG_RDV_TOKEN')
     if tok is None:
-        if not _is_loopback(addr):
-            raise RuntimeError('rendezvous on %s: set PMG_RDV_TOKEN to a secret shared by the ranks (the derived token only '
-                               'protects a loopback rendezvous against stale peers)' % addr)
+        if not _is_local_address(addr) and os.environ.get('PMG_RDV_SINGLE_NODE') != '1':
+            raise RuntimeError('rendezvous on %s, which is not an address of this machine: set PMG_RDV_TOKEN to a secret shared by '
+                               'the ranks (the derived token only protects a single-node rendezvous against stale peers; a '
+                               'single-node launcher whose master address does not resolve here can say PMG_RDV_SINGLE_NODE=1)' % addr)
         tok = '|'.join(os.environ.get(k, '') for k in ('TORCHELASTIC_RUN_ID', 'MASTER_ADDR', 'MASTER_PORT', 'PMG_RDV_PORT', 'WORLD_SIZE'))
     return hashlib.sha256(('pmg-rdv:' + tok).encode()).digest()
 

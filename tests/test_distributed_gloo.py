@@ -211,6 +211,38 @@ def test_rendezvous_drops_strangers_and_never_unpickles(built):
     rdv.close()
 
 
+def test_job_token_accepts_a_hostname_master_address_of_this_machine(monkeypatch):
+    """A single-node launcher may export the node's host name or FQDN as MASTER_ADDR (torchrun --standalone, SLURM wrappers):
+    an address that resolves to one of this machine's interfaces takes the derived token like loopback does; an address of
+    ANOTHER machine needs PMG_RDV_TOKEN (or the launcher's word, PMG_RDV_SINGLE_NODE=1, when its name does not resolve here)."""
+    import socket
+    from pybullet_multigoal_gym_amd import distributed as D
+    monkeypatch.delenv('PMG_RDV_TOKEN', raising=False)
+    monkeypatch.delenv('PMG_RDV_SINGLE_NODE', raising=False)
+    real = socket.getaddrinfo
+
+    def fake(host, *a, **k):
+        if host == 'node17.cluster.example':
+            return [(socket.AF_INET, socket.SOCK_STREAM, 6, '', ('127.0.0.1', 0))]     # this node's own name
+        if host == 'head.cluster.example':
+            return [(socket.AF_INET, socket.SOCK_STREAM, 6, '', ('203.0.113.7', 0))]   # TEST-NET-3: nobody's interface
+        if host == 'nowhere.invalid':
+            raise socket.gaierror('no such host')
+        return real(host, *a, **k)
+    monkeypatch.setattr(socket, 'getaddrinfo', fake)
+    assert D._is_local_address('127.0.0.1') and D._is_local_address('localhost') and D._is_local_address('node17.cluster.example')
+    assert not D._is_local_address('head.cluster.example') and not D._is_local_address('nowhere.invalid')
+    monkeypatch.setenv('MASTER_ADDR', 'node17.cluster.example')
+    assert len(D.job_token('node17.cluster.example')) == 32
+    with pytest.raises(RuntimeError, match='PMG_RDV_TOKEN'):
+        D.job_token('head.cluster.example')
+    monkeypatch.setenv('PMG_RDV_SINGLE_NODE', '1')
+    assert len(D.job_token('nowhere.invalid')) == 32
+    monkeypatch.delenv('PMG_RDV_SINGLE_NODE')
+    monkeypatch.setenv('PMG_RDV_TOKEN', 's3cret')
+    assert D.job_token('head.cluster.example') == D.job_token('127.0.0.1')
+
+
 def test_product_never_imports_torch():
     src = ''
     for root in (os.path.join(ROOT, 'pybullet_multigoal_gym_amd'),):

@@ -61,14 +61,15 @@ def test_teacher_forced_single_step_maximum(built, task):
         assert s['p99'] <= 2e-5, (task, name, s)                    # 99 % of all env-steps: float32 rounding
 
 
-# (task, quantity) whose count of gross single steps is NOT within twice the chaos floor, with the cap that holds instead
-# (measured x 1.4; device / floor / float32 oracle of round 4: slide block 17 / 0.5 / 25; chest_push tip 30 / 1 / 36, q_arm
-# 55 / 7.5 / 74, door 13 / 0.5 / 20; chest_pick_and_place tip 59 / 1 / 68, q_arm 125 / 1.5 / 138, door 77 / 3.5 / 81) -- the
-# device has as many as the float32 build of the oracle: float32 arithmetic at degenerate contact geometry (the puck
-# on its rim, the gripper base on the chest's edges; the reference-face flip between nearly parallel faces), tests/test_gpu_scripted.py ABOVE_FLOOR
-ABOVE_FLOOR = {('slide', 'block_pos'): 35, ('chest_push', 'tip_pos'): 60, ('chest_push', 'q_arm'): 115, ('chest_push', 'door_q'): 30,
-               ('chest_pick_and_place', 'tip_pos'): 120, ('chest_pick_and_place', 'q_arm'): 250, ('chest_pick_and_place', 'door_q'): 160}   # (twice the measurements)
-P99 = {('chest_pick_and_place', 'q_arm'): 1.2e-4}     # 0.24 % of its steps are gross: the p99 sits on their edge (8.3e-5)
+# (task, quantity) whose count of gross single steps is NOT within twice the chaos floor + 3, with the cap that holds instead
+# (the measurement x 1.2).  Round 4's list (caps 35 ... 250: as many gross steps as the float32 oracle, 10-100 x the floor) shrank
+# with the float32-robust predicates of the cylinder narrowphase; measured in round 5, device / floor of 51 200
+# steps (profiles/r05_chaos_floor.txt): slide block 15 / 0; chest_push tip 1 / 0, q_arm 17 / 7.5, door 1 / 1.5;
+# chest_pick_and_place tip 5 / 2, q_arm 16 / 2.5, door 8 / 2.5 (round 4: 17; 30, 55, 13; 59, 125, 77).  The rest is float32
+# arithmetic between the kinematics and the narrowphase at degenerate cylinder contacts: with both in double (cyl_redo64, off
+# by default for its cost) the device measured slide 0 / 0.
+ABOVE_FLOOR = {('slide', 'block_pos'): 18, ('chest_push', 'q_arm'): 21, ('chest_pick_and_place', 'q_arm'): 20, ('chest_pick_and_place', 'door_q'): 10}
+P99 = {}
 
 
 @pytest.mark.parametrize('task', RELATIVE)
