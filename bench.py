@@ -221,8 +221,15 @@ def main():
     if multi:
         # PMG_BENCH_FORCE_COMM_FAIL: test hook for the fallback below
         if init_rccl(env, rdv, _force_fail=bool(os.environ.get('PMG_BENCH_FORCE_COMM_FAIL'))):
-            gathered = h.device_alloc(world * N * env.dims.packed_dim * 4)
-            collective = 'one RCCL all-gather of the packed obs rows per step (%d B per rank)' % (N * env.dims.packed_dim * 4)
+            # the all-gather of step t runs on the library's communication stream beside step t + 1 (pmg_comm_overlap: packed rows
+            # double-buffered; the gathered tables alternate too, as a consumer of table t would need while gather t + 1 is in
+            # flight).  PMG_BENCH_NO_OVERLAP=1: the in-stream all-gather of rounds 1-4, for A/B
+            overlap = not os.environ.get('PMG_BENCH_NO_OVERLAP')
+            gathered = [h.device_alloc(world * N * env.dims.packed_dim * 4) for _ in range(2 if overlap else 1)]
+            if overlap:
+                h.comm_overlap(True)
+            collective = 'one RCCL all-gather of the packed obs rows per step (%d B per rank), %s' % (
+                N * env.dims.packed_dim * 4, 'on a communication stream, overlapped with the next step' if overlap else 'in the step stream')
         else:
             # every rank takes the SAME fallback, and the JSON line says so: packed rows to the host, TCP all-gather
             collective = 'FALLBACK: RCCL init failed, host all-gather of packed obs (PCIe + TCP inclusive)'
@@ -256,8 +263,10 @@ def main():
                 h.reset_device(masks + ((t + 1) % T) * N)  # untimed pre-roll: the mask table sets up the staggered phases
             elif stagger:
                 h.reset_done_device()                      # from then on the envs whose TimeLimit ran out reset themselves on the device
-            if gathered is not None:
-                h.allgather_packed(gathered)
+            if gathered is not None and len(gathered) == 2:
+                h.allgather_packed_async(gathered[t & 1])
+            elif gathered is not None:
+                h.allgather_packed(gathered[0])
             elif host_gather:
                 h.sync()
                 tg = time.perf_counter()
@@ -419,7 +428,8 @@ def main():
     if masks is not None:
         h.device_free(masks)
     if gathered is not None:
-        h.device_free(gathered)
+        for g in gathered:
+            h.device_free(g)
     env.close()
     if rdv is not None:
         rdv.barrier()

@@ -199,6 +199,17 @@ int pmg_comm_unique_id(uint8_t id[128]);
 int pmg_comm_init(pmg_env* env, int rank, int nranks, const uint8_t id[128]);
 /* d_gathered: [nranks*N, packed_dim] device buffer (caller-owned). */
 int pmg_allgather_packed(pmg_env* env, float* d_gathered);
+/* The same, OVERLAPPED with the next step (the collective must not add to the step).  pmg_comm_overlap(env, 1)
+ * double-buffers the packed rows: step t writes buffer t & 1 (PMG_BUF_PACKED / pmg_device_ptr then names the buffer of the
+ * LAST step: query it per step, or read the gathered rows).  pmg_allgather_packed_async enqueues ncclAllGather on the handle's own
+ * communication stream behind the rows of the last step (+ the masked resets enqueued since); the step stream does not wait
+ * for it -- only the step that writes the same row buffer again (two steps later) does.  d_gathered must stay untouched
+ * until pmg_allgather_wait: host != 0 blocks the caller until the LAST enqueued all-gather has completed, host == 0 makes the
+ * handle's stream wait for it (for consumers enqueued on pmg_stream()).  A caller that consumes gather t while gather t + 1 is in
+ * flight alternates two d_gathered buffers.  pmg_sync() also waits for the communication stream. */
+int pmg_comm_overlap(pmg_env* env, int32_t enabled);
+int pmg_allgather_packed_async(pmg_env* env, float* d_gathered);
+int pmg_allgather_wait(pmg_env* env, int32_t host);
 
 /* Device-buffer helpers for callers that have no HIP runtime of their own (e.g. a numpy-only
  * host): allocate / free / copy on the handle's device and stream.  Callers that already own

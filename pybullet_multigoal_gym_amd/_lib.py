@@ -48,7 +48,7 @@ class PmgLibrary:
     SYMBOLS = ['pmg_create', 'pmg_destroy', 'pmg_device_count', 'pmg_get_dims', 'pmg_last_error', 'pmg_seed', 'pmg_reset', 'pmg_step',
                'pmg_reset_device', 'pmg_reset_done_device', 'pmg_step_device', 'pmg_device_ptr', 'pmg_stream', 'pmg_sync', 'pmg_read_outputs',
                'pmg_compute_reward', 'pmg_compute_reward_device', 'pmg_get_state', 'pmg_set_state', 'pmg_set_goal',
-               'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_timing_reset', 'pmg_timing_every', 'pmg_timing_read',
+               'pmg_comm_unique_id', 'pmg_comm_init', 'pmg_allgather_packed', 'pmg_comm_overlap', 'pmg_allgather_packed_async', 'pmg_allgather_wait', 'pmg_timing_reset', 'pmg_timing_every', 'pmg_timing_read',
                'pmg_device_alloc', 'pmg_device_free', 'pmg_upload', 'pmg_download',
                'pmg_set_sub_goal', 'pmg_curriculum_update', 'pmg_curriculum_read', 'pmg_timing_stats', 'pmg_get_rng', 'pmg_set_rng', 'pmg_comm_timing']
 
@@ -302,3 +302,13 @@ class PmgHandle:
 
     def allgather_packed(self, d_out_ptr):
         self._check(self.L.lib.pmg_allgather_packed(self.h, C.c_void_p(d_out_ptr)))
+
+    def comm_overlap(self, enabled=True):
+        """Double-buffer the packed rows so that allgather_packed_async() of step t runs beside step t + 1 (include/pmg.h)."""
+        self._check(self.L.lib.pmg_comm_overlap(self.h, C.c_int32(1 if enabled else 0)))
+
+    def allgather_packed_async(self, d_out_ptr):
+        self._check(self.L.lib.pmg_allgather_packed_async(self.h, C.c_void_p(d_out_ptr)))
+
+    def allgather_wait(self, host=True):
+        self._check(self.L.lib.pmg_allgather_wait(self.h, C.c_int32(1 if host else 0)))

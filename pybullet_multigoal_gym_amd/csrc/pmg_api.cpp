@@ -124,6 +124,16 @@ struct pmg_env {
     int two_wave = 1;                 /* reach: the two-wavefront kernel for steps with contact-prone envs (PMG_REACH_TWO_WAVES=0: never) */
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0;
+    /* overlapped all-gather (pmg_comm_overlap): the packed rows are double-buffered -- step t writes out2[t & 1], its all-gather
+     * reads that buffer on the communication stream while step t + 1 computes and writes the OTHER one; step t + 2, which
+     * writes out2[t & 1] again, is the one that waits for gather t */
+    bool overlap = false;
+    float* out2[2] = {nullptr, nullptr};
+    int out_phase = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_rows[2] = {nullptr, nullptr}, ev_gdone[2] = {nullptr, nullptr};
+    bool gpending[2] = {false, false};
+    int last_gather = -1;
     char err[512] = "";
 };
 
@@ -439,7 +449,7 @@ void pmg_destroy(pmg_env* e)
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm) ncclCommDestroy(e->comm);
-    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); (void)hipFree(e->P.out); (void)hipFree(e->P.sched); if (e->P.env_cycles) (void)hipFree(e->P.env_cycles);
+    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); if (e->out2[0]) { (void)hipFree(e->out2[0]); (void)hipFree(e->out2[1]); } else (void)hipFree(e->P.out); (void)hipFree(e->P.sched); if (e->P.env_cycles) (void)hipFree(e->P.env_cycles);
     (void)hipFree(e->d_actions); (void)hipFree(e->d_mask);
     (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
     if (e->h_packed) (void)hipHostFree(e->h_packed);
@@ -449,6 +459,8 @@ void pmg_destroy(pmg_env* e)
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->ev_join) (void)hipEventDestroy(e->ev_join);
     if (e->side) { (void)hipStreamSynchronize(e->side); (void)hipStreamDestroy(e->side); }
+    if (e->comm_stream) { (void)hipStreamSynchronize(e->comm_stream); (void)hipStreamDestroy(e->comm_stream); }
+    for (int b = 0; b < 2; b++) { if (e->ev_rows[b]) (void)hipEventDestroy(e->ev_rows[b]); if (e->ev_gdone[b]) (void)hipEventDestroy(e->ev_gdone[b]); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -499,6 +511,13 @@ int pmg_step_device(pmg_env* e, const float* d_actions)
     if (!e || !d_actions) return PMG_E_INVALID;
     if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_step: reset() must be called (for all envs) before the first step()");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (e->overlap) {
+        /* this step writes the other row buffer; the all-gather that last read it (two steps ago) must be through */
+        const int b = e->out_phase ^ 1;
+        if (e->gpending[b]) { HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_gdone[b], 0)); e->gpending[b] = false; }
+        e->out_phase = b;
+        e->P.out = e->out2[b];
+    }
     const bool timed = (e->step_count++ % e->ev_every) == 0;
     if (timed && e->ev_n == EVENT_POOL) drain_events(e);
     int i = timed ? e->ev_n++ : 0;
@@ -583,6 +602,7 @@ int pmg_sync(pmg_env* e)
     if (!e) return PMG_E_INVALID;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->comm_stream) HIP_TRY(e, hipStreamSynchronize(e->comm_stream));   /* (an overlapped all-gather in flight) */
     return PMG_OK;
 }
 
@@ -797,6 +817,68 @@ int pmg_allgather_packed(pmg_env* e, float* d_gathered)
     if (rc != ncclSuccess) return fail(e, PMG_E_COMM, "ncclAllGather -> %s", ncclGetErrorString(rc));
     HIP_TRY(e, hipEventRecord(e->cv_b[i], e->stream));
     e->cv_n = i + 1;
+    return PMG_OK;
+}
+
+int pmg_comm_overlap(pmg_env* e, int32_t enabled)
+{
+    if (!e) return PMG_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (!enabled) {
+        if (e->overlap) {
+            if (e->comm_stream) HIP_TRY(e, hipStreamSynchronize(e->comm_stream));
+            e->gpending[0] = e->gpending[1] = false;
+            e->last_gather = -1;
+        }
+        e->overlap = false;       /* (the rows stay where the last step wrote them: P.out keeps pointing at that buffer) */
+        return PMG_OK;
+    }
+    if (!e->out2[0]) {
+        const size_t bytes = (size_t)e->dims.num_envs * e->dims.packed_dim * sizeof(float);
+        e->out2[0] = e->P.out;
+        if (hipMalloc((void**)&e->out2[1], bytes) != hipSuccess) return fail(e, PMG_E_NOMEM, "pmg_comm_overlap: hipMalloc(%zu) failed", bytes);
+        HIP_TRY(e, hipMemcpyAsync(e->out2[1], e->out2[0], bytes, hipMemcpyDeviceToDevice, e->stream));
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_rows[b], hipEventDisableTiming));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_gdone[b], hipEventDisableTiming));
+        }
+        e->out_phase = 0;
+    }
+    e->overlap = true;
+    return PMG_OK;
+}
+int pmg_allgather_packed_async(pmg_env* e, float* d_gathered)
+{
+    if (!e || !d_gathered) return PMG_E_INVALID;
+    if (!e->comm) return fail(e, PMG_E_STATE, "pmg_allgather_packed_async: pmg_comm_init was not called");
+    if (!e->overlap) return fail(e, PMG_E_STATE, "pmg_allgather_packed_async: pmg_comm_overlap(env, 1) first");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const size_t count = (size_t)e->dims.num_envs * e->dims.packed_dim;
+    const int b = e->out_phase;
+    if (e->cv_n == EVENT_POOL) drain_comm_events(e);
+    const int i = e->cv_n;
+    /* rows of this step (and of the masked resets behind it) are complete on the step's stream -> the communication stream
+     * may read them; nothing else of the step's stream waits for the transfer */
+    HIP_TRY(e, hipEventRecord(e->ev_rows[b], e->stream));
+    HIP_TRY(e, hipStreamWaitEvent(e->comm_stream, e->ev_rows[b], 0));
+    HIP_TRY(e, hipEventRecord(e->cv_a[i], e->comm_stream));
+    ncclResult_t rc = ncclAllGather(e->out2[b], d_gathered, count, ncclFloat, e->comm, e->comm_stream);
+    if (rc != ncclSuccess) return fail(e, PMG_E_COMM, "ncclAllGather -> %s", ncclGetErrorString(rc));
+    HIP_TRY(e, hipEventRecord(e->cv_b[i], e->comm_stream));
+    HIP_TRY(e, hipEventRecord(e->ev_gdone[b], e->comm_stream));
+    e->cv_n = i + 1;
+    e->gpending[b] = true;
+    e->last_gather = b;
+    return PMG_OK;
+}
+int pmg_allgather_wait(pmg_env* e, int32_t host)
+{
+    if (!e) return PMG_E_INVALID;
+    if (e->last_gather < 0) return PMG_OK;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (host) HIP_TRY(e, hipEventSynchronize(e->ev_gdone[e->last_gather]));
+    else HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_gdone[e->last_gather], 0));
     return PMG_OK;
 }
 

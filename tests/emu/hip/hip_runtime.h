@@ -4,12 +4,29 @@
 #define PMG_FAKE_HIP_RUNTIME_H
 #include "../hip_emu.h"
 #include <chrono>
+#include <deque>
+#include <functional>
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorUnknown = 999 };
-typedef struct emu_stream_s* hipStream_t;
-struct emu_event_s { std::chrono::steady_clock::time_point t; };
+/* Streams.  The emulator runs every launch in order at the call -- except on a NON-BLOCKING stream when PMG_EMU_LAZY_COMM=1: work
+ * enqueued there (the product's communication stream: the overlapped all-gather) is DEFERRED until somebody depends on it --
+ * a wait on one of its events, a synchronise -- i.e. it runs as LATE as the recorded dependencies allow.  A missing dependency
+ * (the next step overwriting the rows an all-gather has yet to read) then shows up as wrong data instead of hiding behind the
+ * emulator's in-order execution (tests/test_distributed_gloo.py). */
+struct emu_event_s;
+struct emu_stream_s {
+    bool lazy = false;
+    std::deque<std::function<void()>> q;
+    void flush() { while (!q.empty()) { auto f = std::move(q.front()); q.pop_front(); f(); } }
+    void flush_until(emu_event_s* e);
+};
+typedef emu_stream_s* hipStream_t;
+struct emu_event_s { std::chrono::steady_clock::time_point t; emu_stream_s* pending = nullptr; };
+inline void emu_stream_s::flush_until(emu_event_s* e) { while (e->pending == this && !q.empty()) { auto f = std::move(q.front()); q.pop_front(); f(); } }
 typedef emu_event_s* hipEvent_t;
+/* enqueue on a stream: now, or deferred on a lazy one */
+template <class F> static inline void emu_enqueue(hipStream_t s, F&& f) { if (s && s->lazy) s->q.emplace_back(std::forward<F>(f)); else f(); }
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
@@ -33,17 +50,40 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags)
+{
+    const char* lz = getenv("PMG_EMU_LAZY_COMM");
+    *s = new emu_stream_s();
+    (*s)->lazy = (flags & hipStreamNonBlocking) && lz && atoi(lz) != 0;
+    return hipSuccess;
+}
+static inline hipError_t hipStreamDestroy(hipStream_t s) { if (s) { s->flush(); delete s; } return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { if (s) s->flush(); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event_s(); return hipSuccess; }
 enum { hipEventDisableTiming = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event_s(); return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; } /* the emulator runs everything in order */
-static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+/* an eager stream runs in order at the call: a wait on an event of a lazy stream runs that stream up to the event NOW; a lazy
+ * stream that waits (for an event of an eager stream: complete since its record; of a lazy one: run it that far) defers the wait */
+static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+    if (s && s->lazy) { s->q.emplace_back([e]() { if (e->pending) e->pending->flush_until(e); }); return hipSuccess; }
+    if (e->pending) e->pending->flush_until(e);
+    return hipSuccess;
+}
+static inline hipError_t hipEventDestroy(hipEvent_t e) { if (e->pending) e->pending->flush_until(e); delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
+{
+    if (s && s->lazy) { if (e->pending && e->pending != s) e->pending->flush_until(e); e->pending = s; s->q.emplace_back([e]() { e->t = std::chrono::steady_clock::now(); e->pending = nullptr; }); return hipSuccess; }
+    if (e->pending) e->pending->flush_until(e);
+    e->t = std::chrono::steady_clock::now();
+    return hipSuccess;
+}
+static inline hipError_t hipEventSynchronize(hipEvent_t e) { if (e->pending) e->pending->flush_until(e); return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
 {
+    if (a->pending) a->pending->flush_until(a);
+    if (b->pending) b->pending->flush_until(b);
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }

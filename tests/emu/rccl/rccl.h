@@ -13,6 +13,7 @@
 #include <sys/mman.h>
 #include <sys/time.h>
 #include <unistd.h>
+#include <hip/hip_runtime.h>
 typedef struct { char internal[128]; } ncclUniqueId;
 struct emu_comm_s {
     char name[128];
@@ -66,14 +67,20 @@ static inline ncclResult_t ncclCommDestroy(ncclComm_t m)
     return ncclSuccess;
 }
 static inline const char* ncclGetErrorString(ncclResult_t) { return "emulated rccl failure"; }
-static inline ncclResult_t ncclAllGather(const void* s, void* d, size_t count, ncclDataType_t, ncclComm_t m, void*)
+static inline void emu_allgather_now(const void* s, void* d, size_t b, ncclComm_t m)
 {
-    size_t b = count * 4;
-    if (b > EMU_SLOT_BYTES) return ncclUnhandled;
     memcpy(m->base + EMU_HDR_BYTES + (size_t)m->rank * EMU_SLOT_BYTES, s, b);
     emu_barrier(m);
     for (int r = 0; r < m->n; r++) memcpy((unsigned char*)d + (size_t)r * b, m->base + EMU_HDR_BYTES + (size_t)r * EMU_SLOT_BYTES, b);
     emu_barrier(m);
+}
+/* stream-ordered like the real one: on a lazy stream of the fake HIP runtime (hip/hip_runtime.h) the copy is deferred with
+ * the rest of that stream's work -- every rank defers and flushes at the same points of the same program */
+static inline ncclResult_t ncclAllGather(const void* s, void* d, size_t count, ncclDataType_t, ncclComm_t m, hipStream_t stream)
+{
+    size_t b = count * 4;
+    if (b > EMU_SLOT_BYTES) return ncclUnhandled;
+    emu_enqueue(stream, [=]() { emu_allgather_now(s, d, b, m); });
     return ncclSuccess;
 }
 #endif

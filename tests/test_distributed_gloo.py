@@ -54,6 +54,90 @@ def _worker(rank, world, port, total, ret):
     dist.destroy_process_group()
 
 
+def _overlap_worker(rank, world, port, total, steps, broken):
+    """Two ranks, overlapped all-gather on the emulator with a LAZY communication stream (the all-gather runs as late as its
+    recorded dependencies allow): every gathered table must hold the rows of ITS step from every rank."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['PMG_EMU_LAZY_COMM'] = '1'
+    import pybullet_multigoal_gym_amd as pmg
+    from pybullet_multigoal_gym_amd import distributed as D
+    from pybullet_multigoal_gym_amd._lib import PmgLibrary
+    rdv = D.Rendezvous(rank, world, addr='127.0.0.1', port=port)
+    emu = PmgLibrary(os.path.join(ROOT, 'tests', 'emu', 'libpmg_emu.so'))
+    env = D.make_sharded_env(pmg.make_env, total, world, rank, task='reach', seed=11, seed_stride=1, max_episode_steps=3, _library=emu)
+    start, stop = D.shard_bounds(total, world, rank)
+    n, S = stop - start, env.dims.packed_dim
+    assert D.init_rccl(env, rdv)
+    h = env.handle
+    if not broken:
+        h.comm_overlap(True)
+    env.reset()
+    rs = np.random.RandomState(7)
+    tables = [h.device_alloc(total * S * 4) for _ in range(2)]
+    acts = h.device_alloc(n * 3 * 4)
+    mine, got = [], []
+    ptrs = set()
+    for t in range(steps):
+        a = rs.uniform(-1, 1, (total, 3)).astype(np.float32)[start:stop]
+        h.upload(acts, np.ascontiguousarray(a))
+        h.step_device(acts)
+        h.reset_done_device()                                   # TimeLimit resets of the step belong to its rows
+        rows = np.empty((n, S), np.float32)
+        h.download(rows, h.device_ptr())                       # the rows of THIS step (the buffer of the last step)
+        ptrs.add(h.device_ptr())
+        mine.append(rows)
+        if broken:
+            # the schedule WITHOUT the double buffer and its dependency (what "enqueue the gather on another stream" alone would
+            # be): emulated by gathering one step late from the single row buffer -- the check below must catch it
+            if t > 0:
+                h.allgather_packed(tables[(t - 1) & 1])
+                g = np.empty((total, S), np.float32)
+                h.download(g, tables[(t - 1) & 1])
+                got.append(g)
+            continue
+        h.allgather_packed_async(tables[t & 1])               # nothing waits for it here: step t + 1 is enqueued right behind
+    if not broken:
+        h.allgather_wait(host=True)
+        assert len(ptrs) == 2                                   # the rows alternate between two buffers
+        last = np.empty((total, S), np.float32)
+        h.download(last, tables[(steps - 1) & 1])
+        prev = np.empty((total, S), np.float32)
+        h.download(prev, tables[(steps - 2) & 1])
+        got = {steps - 1: last, steps - 2: prev}
+    else:
+        got = {t: g for t, g in enumerate(got)}
+    hist = D.allgather_host(np.stack(mine), rdv)                # [world * steps_block ...]: every rank's rows of every step
+    hist = hist.reshape(world, steps, n, S)
+    bad = 0
+    for t, g in got.items():
+        want = np.concatenate([hist[r, t] for r in range(world)], axis=0)
+        bad += int(not np.array_equal(g, want))
+    if not broken:
+        assert h.comm_timing()[2] == steps                      # events around every overlapped all-gather, as around the in-stream one
+    rdv.barrier()
+    for p in tables + [acts]:
+        h.device_free(p)
+    env.close()
+    rdv.close()
+    if broken:
+        assert bad > 0, 'the late single-buffer gather went unnoticed: the check has no teeth'
+    else:
+        assert bad == 0, 'an overlapped all-gather delivered rows of another step'
+
+
+@pytest.mark.parametrize('broken', [False, True])
+def test_overlapped_allgather_delivers_the_rows_of_its_step(built, broken):
+    """pmg_comm_overlap + pmg_allgather_packed_async: the all-gather of step t runs on the communication stream beside step
+    t + 1, which writes the OTHER row buffer; step t + 2 waits for it.  On the emulator the communication stream is lazy
+    (PMG_EMU_LAZY_COMM=1: its work runs only when something depends on it, i.e. as late as the recorded events allow), so a
+    missing dependency delivers the wrong step's rows.  broken=True replays the naive schedule (single row buffer, the gather
+    one step late) to show that the check catches it."""
+    import torch.multiprocessing as mp
+    port = 33000 + os.getpid() % 2000 + (1 if broken else 0)
+    mp.spawn(_overlap_worker, args=(2, port, 4, 5, broken), nprocs=2, join=True)
+
+
 def test_two_rank_shards_equal_one_unsharded_env(built, tmp_path):
     import torch.multiprocessing as mp
     import oracle_lib as O
