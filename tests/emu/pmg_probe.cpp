@@ -68,6 +68,28 @@ extern "C" int pmge_probe_narrowphase(int kind, const float* ca, const float* Ra
     return pmg::cyl_box(ca, Ra, ha[0], ha[2], cb, Rb, hb[0], hb[1], hb[2], margin, out, W);
 }
 
+/* the double-precision repeat of a cylinder pair (cyl_redo64) and its pieces, called directly: the double forward kinematics of a
+ * contact body's link, and the repeat itself for chest kind ck (-1: none).  amb_out (may be NULL): the ambiguity of the FLOAT
+ * pass over the same pair taken from float poses (ca, Ra | cb, Rb given by the caller), the trigger of the repeat */
+extern "C" void pmge_probe_fk64(const float* q9, int body, double* p, double* R) { pmg::fk64_link(q9, body, p, R); }
+extern "C" int pmge_probe_cyl_redo64(int ck, int cyl_body, int box_body, int wall, const float* q9, const float* cyl_blk, const float* box_blk,
+                                     const float* doorq, const float* box_cf, const float* box_hf, float rad, float hl, float* out)
+{
+    alignas(16) static float W[256];
+    if (ck == 0) return pmg::cyl_redo64<0>(cyl_body, box_body, wall, q9, cyl_blk, box_blk, doorq, box_cf, box_hf, rad, hl, out, W);
+    if (ck == 1) return pmg::cyl_redo64<1>(cyl_body, box_body, wall, q9, cyl_blk, box_blk, doorq, box_cf, box_hf, rad, hl, out, W);
+    return pmg::cyl_redo64<-1>(cyl_body, box_body, wall, q9, cyl_blk, box_blk, doorq, box_cf, box_hf, rad, hl, out, W);
+}
+extern "C" int pmge_probe_cyl_amb(const float* ca, const float* Ra, float rad, float hl, const float* cb, const float* Rb, const float* hb, float margin,
+                                  float* out, float* amb_out)
+{
+    alignas(16) static float W[256];
+    float amb = 1e30f;
+    const int n = pmg::cyl_box(ca, Ra, rad, hl, cb, Rb, hb[0], hb[1], hb[2], margin, out, W, &amb);
+    *amb_out = amb;
+    return n;
+}
+
 /* the launch-order plan in isolation: the single-workgroup plan (two_pass = 0) or the two-pass multi-workgroup plan on
  * the same batch; sched_out = [3 + 3 N] as on the device; returns the plan's promotion flag (< 0: not run).  hot: [N, 32] state rows, blocks: [N, 13 nb], actions [N, adim] */
 extern "C" int pmge_probe_plan(int n_envs, int nb, const float* hot, const float* blocks, const float* actions, int adim,

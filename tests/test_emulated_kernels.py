@@ -552,3 +552,79 @@ def test_emulated_sharded_batch_is_bit_identical_to_the_unsharded_batch(emu_libr
     (tests/test_gpu_parity.py runs the same at 512 / 2 and 4096 / 8 on the device)."""
     from test_gpu_parity import _sharded_equals_unsharded
     _sharded_equals_unsharded(emu_library, task, 24, 3, 4)
+
+
+def _quat_R64(q):
+    x, y, z, w = [float(v) for v in q]
+    s = 2.0 / (x * x + y * y + z * z + w * w)
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz, xx, xy, xz, yy, yz, zz = w * xs, w * ys, w * zs, x * xs, x * ys, x * zs, y * ys, y * zs, z * zs
+    return np.array([[1 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1 - (xx + yy)]])
+
+
+def test_double_forward_kinematics_of_the_contact_links_matches_the_oracle(emu_library):
+    """fk64_link (the double poses cyl_redo64 takes for the gripper base and the fingers, from float32 joint angles) against
+    the float64 oracle's kinematics() through its Bullet-call-level world: link frames of Bullet links 12 / 13 / 15."""
+    lib = C.CDLL(emu_library.path)
+    ora = O.OracleEnv('reach', 1, seed_base=0)
+    ora.reset()
+    ol = ora.lib
+    rs = np.random.RandomState(3)
+    for trial in range(20):
+        q = np.float32(np.concatenate([rs.uniform(-2, 2, 7), rs.uniform(0, 0.035, 2)]))
+        for d in range(9):
+            ol.pmgo_bw_reset_joint(ora.h, 0, d, C.c_double(float(q[d])), C.c_double(0.0))
+        for body, link in ((7, 12), (5, 13), (6, 15)):                 # BODY_GBASE, BODY_FINGER1, BODY_FINGER2
+            p, R, ref = np.zeros(3), np.zeros(9), np.zeros(13)
+            lib.pmge_probe_fk64(_fp(q), body, _fp(p), _fp(R))
+            ol.pmgo_bw_link_state(ora.h, link, _fp(ref))
+            assert np.abs(p - ref[:3]).max() < 1e-12, (trial, body, p, ref[:3])
+            assert np.abs(R.reshape(3, 3) - _quat_R64(ref[3:7])).max() < 1e-12
+    ora.close()
+
+
+def test_double_repeat_of_a_cylinder_pair_is_the_float64_oracle(emu_library):
+    """cyl_redo64 (cyl_box<double> on poses re-derived in double from the float32 state) against the float64 oracle's cyl_box on
+    the same poses: the slide puck -- any small tilt, any yaw -- against the table and near its edge.  Same count, points and
+    normals to 1e-6 (the outputs are float32), depths to 1e-9 relative to the scene; and the float pass flags the knife edges:
+    its ambiguity is below 1 wherever the float32 pass's own answer differs grossly from the oracle's."""
+    lib = C.CDLL(emu_library.path)
+    lib.pmge_probe_cyl_redo64.restype = C.c_int
+    lib.pmge_probe_cyl_amb.restype = C.c_int
+    rs = np.random.RandomState(5)
+    I3 = np.eye(3)
+    checked = flagged = gross_unflagged = 0
+    q9 = np.zeros(9, np.float32)
+    door = np.zeros(4, np.float32)
+    for trial in range(300):
+        tilt = 10.0 ** rs.uniform(-8, -1.5) * rs.normal(size=2)
+        yaw = rs.uniform(0, 2 * np.pi)
+        quat = np.array([tilt[0] / 2, tilt[1] / 2, np.sin(yaw / 2), np.cos(yaw / 2)])
+        quat /= np.linalg.norm(quat)
+        edge = trial % 3 == 0
+        blk = np.zeros(13, np.float32)
+        blk[0:3] = [-0.70 + (0.5 - rs.uniform(0, 0.04) if edge else rs.uniform(-0.3, 0.3)), rs.uniform(-0.3, 0.3), 0.16 + 0.01 + rs.uniform(-2e-4, 1.5e-3)]
+        blk[3:7] = quat
+        tc, th = np.float32([-0.70, 0.0, 0.08]), np.float32([0.5, 0.45, 0.08])
+        out = np.zeros(40, np.float32)
+        n = lib.pmge_probe_cyl_redo64(-1, 0, -1, -1, _fp(q9), _fp(blk), _fp(blk), _fp(door), _fp(tc), _fp(th), C.c_float(0.03), C.c_float(0.01), _fp(out))
+        R = _quat_R64(blk[3:7])
+        ref = O.cyl_box(blk[0:3].astype(float), R.ravel(), 0.03, 0.01, tc.astype(float), I3.ravel(), th.astype(float))
+        assert n == len(ref), (trial, n, len(ref))
+        if n == 0:
+            continue
+        got = out.reshape(4, 10)[:n]
+        assert np.abs(got[:, 6:9] - ref[:, 6:9]).max() < 1e-6 and np.abs(got[:, 9] - ref[:, 9]).max() < 1e-8 and np.abs(got[:, 0:6] - ref[:, 0:6]).max() < 1e-6, (trial, got, ref)
+        checked += 1
+        Rf = np.float32(R)                                     # the float pass: float32 poses
+        outf, amb = np.zeros(40, np.float32), C.c_float(0)
+        nf = lib.pmge_probe_cyl_amb(_fp(blk), _fp(Rf), C.c_float(0.03), C.c_float(0.01), _fp(tc), _fp(np.float32(I3)), _fp(th), C.c_float(0.002), _fp(outf), C.byref(amb))
+        gf = outf.reshape(4, 10)[:nf]
+        # gross: another number of points, another normal, a point 3 mm from the oracle's or 20 um deeper (two candidates of the
+        # same depth 1 mm apart on the rim may swap in the reduction to four points: not a different contact)
+        gross = nf != n or np.abs(np.sort(gf[:, 0:3], axis=0) - np.sort(ref[:, 0:3], axis=0)).max() > 3e-3 or np.abs(gf[0, 6:9] - ref[0, 6:9]).max() > 1e-2 \
+            or np.abs(np.sort(gf[:, 9]) - np.sort(ref[:, 9])).max() > 2e-5
+        flagged += int(amb.value < 1.0)
+        gross_unflagged += int(gross and not amb.value < 1.0)
+    print('cylinder pairs in contact %d, float pass flagged ambiguous %d, gross float32 answers not flagged %d' % (checked, flagged, gross_unflagged))
+    assert checked > 150 and gross_unflagged == 0 and flagged < 0.5 * checked
