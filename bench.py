@@ -205,9 +205,13 @@ def main():
     device = local_rank
     try:
         ndev = PmgLibrary(args.lib).device_count()
-        if ndev > 0 and local_rank >= ndev:
-            device = local_rank % ndev
-            print('bench.py: rank %d sees %d device(s); using device %d' % (rank, ndev, device), file=sys.stderr)
+        if ndev == 1 and local_rank >= 1:
+            device = 0
+            print('bench.py: rank %d sees one device (per-rank visibility); using device 0' % rank, file=sys.stderr)
+        elif ndev > 1 and local_rank >= ndev:
+            # more ranks than visible GPUs on a node that shows several: two ranks would share a device -- RCCL fails or hangs
+            # on a duplicate GPU, and a weak-scaling number from shared devices would mislead
+            sys.exit('bench.py: rank %d has LOCAL_RANK %d but only %d devices are visible: refusing to share a GPU between ranks' % (rank, local_rank, ndev))
     except Exception:
         pass
     env = pmg.make_env(task=args.task, num_envs=N, num_block=4, device=device, seed=0, seed_stride=1,

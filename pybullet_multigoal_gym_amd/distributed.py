@@ -273,9 +273,16 @@ class Rendezvous:
                     rejected.append(msg)
                     print('rendezvous (rank 0): dropped a connection from ' + msg, file=sys.stderr, flush=True)
                     try:
-                        _send(conn, ['NAK', why])   # a legitimate rank fails fast with the reason instead of timing out
+                        # the reply to the hello: a legitimate rank fails fast instead of timing out.  The REASON goes to rank 0's
+                        # stderr only -- the peer is unauthenticated
+                        _send(conn, 'NAK')
                     except (ConnectionError, OSError):
                         pass
+                    conn.close()
+                    continue
+                try:
+                    _send(conn, 'ACK')              # the handshake: the client reads this reply in its constructor
+                except (ConnectionError, OSError):
                     conn.close()
                     continue
                 conn.settimeout(timeout)
@@ -295,6 +302,16 @@ class Rendezvous:
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
             _send(s, [job_token(addr), self.rank])
+            # the handshake: rank 0 answers the hello with ACK or NAK before any collective -- no sentinel values inside
+            # collective payloads, and a refused rank learns it here, not from a broken pipe in its first all-gather
+            try:
+                reply = _recv(s, max_payload=16)
+            except (ConnectionError, OSError) as ex:
+                s.close()
+                raise ConnectionError('rendezvous: rank 0 closed the connection during the hello (%s)' % type(ex).__name__)
+            if reply != 'ACK':
+                s.close()
+                raise ConnectionError('rendezvous: rank 0 refused this rank (wrong job token, duplicate or out-of-range rank: see rank 0\'s stderr)')
             self.sock = s
 
     @classmethod
@@ -311,10 +328,7 @@ class Rendezvous:
                 _send(c, out)
             return out
         _send(self.sock, obj)
-        out = _recv(self.sock)
-        if isinstance(out, list) and len(out) == 2 and isinstance(out[0], str) and out[0] == 'NAK' and isinstance(out[1], str):
-            raise ConnectionError('rendezvous: rank 0 refused this rank: ' + out[1])
-        return out
+        return _recv(self.sock)
 
     def broadcast(self, obj, src=0):
         return self.allgather(obj if self.rank == src else None)[src]

@@ -273,6 +273,13 @@ def test_rendezvous_drops_strangers_and_never_unpickles(built):
     stranger(D.MAGIC + tag + struct.pack('<I', len(body)) + body)                   # right shape, wrong token
     tag, body = D._encode([D.job_token(), 7])
     stranger(D.MAGIC + tag + struct.pack('<I', len(body)) + body)                   # right token, rank out of range
+    # a legitimate client with the wrong token learns it in its constructor (the handshake), not in its first collective
+    os.environ['PMG_RDV_TOKEN'] = 'not-the-jobs-secret'
+    try:
+        with pytest.raises(ConnectionError, match='refused'):
+            D.Rendezvous(1, 2, addr='127.0.0.1', port=port, timeout=10.0)
+    finally:
+        del os.environ['PMG_RDV_TOKEN']
     peer = D.Rendezvous(1, 2, addr='127.0.0.1', port=port, timeout=30.0)
     th.join(30.0)
     assert not th.is_alive()
