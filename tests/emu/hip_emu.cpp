@@ -7,6 +7,9 @@ emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 float emu_xf[16 * 64 * 16];
 long long pmge_face_clip_calls = 0;
 extern "C" long long pmge_face_clip_count() { return pmge_face_clip_calls; }
+long long pmge_cyl_contact_calls = 0, pmge_cyl_redo_calls = 0;
+extern "C" long long pmge_cyl_contact_count() { return pmge_cyl_contact_calls; }
+extern "C" long long pmge_cyl_redo_count() { return pmge_cyl_redo_calls; }
 
 /* Context switch.  glibc's swapcontext() saves and restores the signal mask with two system calls per switch, and the
  * emulator switches at every cross-lane primitive of every lane; on x86-64 the fibers switch with a dozen instructions

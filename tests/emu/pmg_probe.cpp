@@ -72,13 +72,13 @@ extern "C" int pmge_probe_narrowphase(int kind, const float* ca, const float* Ra
  * contact body's link, and the repeat itself for chest kind ck (-1: none).  amb_out (may be NULL): the ambiguity of the FLOAT
  * pass over the same pair taken from float poses (ca, Ra | cb, Rb given by the caller), the trigger of the repeat */
 extern "C" void pmge_probe_fk64(const float* q9, int body, double* p, double* R) { pmg::fk64_link(q9, body, p, R); }
-extern "C" int pmge_probe_cyl_redo64(int ck, int cyl_body, int box_body, int wall, const float* q9, const float* cyl_blk, const float* box_blk,
-                                     const float* doorq, const float* box_cf, const float* box_hf, float rad, float hl, float* out)
+extern "C" int pmge_probe_cyl_redo64(int ck, int cyl_body, int box_body, int wall, const float* q9, const float* blk0, const float* doorq,
+                                     const float* kc, float prad, float phl, float* out)
 {
     alignas(16) static float W[256];
-    if (ck == 0) return pmg::cyl_redo64<0>(cyl_body, box_body, wall, q9, cyl_blk, box_blk, doorq, box_cf, box_hf, rad, hl, out, W);
-    if (ck == 1) return pmg::cyl_redo64<1>(cyl_body, box_body, wall, q9, cyl_blk, box_blk, doorq, box_cf, box_hf, rad, hl, out, W);
-    return pmg::cyl_redo64<-1>(cyl_body, box_body, wall, q9, cyl_blk, box_blk, doorq, box_cf, box_hf, rad, hl, out, W);
+    if (ck == 0) return pmg::cyl_redo64<0>(cyl_body, box_body, wall, q9, blk0, doorq, kc, prad, phl, out, W);
+    if (ck == 1) return pmg::cyl_redo64<1>(cyl_body, box_body, wall, q9, blk0, doorq, kc, prad, phl, out, W);
+    return pmg::cyl_redo64<-1>(cyl_body, box_body, wall, q9, blk0, doorq, kc, prad, phl, out, W);
 }
 extern "C" int pmge_probe_cyl_amb(const float* ca, const float* Ra, float rad, float hl, const float* cb, const float* Rb, const float* hb, float margin,
                                   float* out, float* amb_out)

@@ -11,7 +11,7 @@
 
 __global__ void __launch_bounds__(64, 2) k(int cas, long long* cyc, float* outp, int* nout)
 {
-    __shared__ float q9[16], blk[16], door[4], out[4 * pmg::CP + 8], W[pmg::BOX_WORK], opsA[12], opsB[12], hb[3], bc[3];
+    __shared__ float q9[16], blk[16], door[4], out[4 * pmg::CP + 8], W[pmg::BOX_WORK], opsA[12], opsB[12], hb[3], bc[3], kc[24];
     const int l = threadIdx.x;
     if (l == 0) {
         const float q[9] = {0.3f, -0.6f, 0.1f, 1.7f, 0.05f, -0.8f, 0.2f, 0.03f, 0.03f};
@@ -19,6 +19,7 @@ __global__ void __launch_bounds__(64, 2) k(int cas, long long* cyc, float* outp,
         blk[0] = -0.5f; blk[1] = 0.02f; blk[2] = 0.17f; blk[3] = 5e-7f; blk[4] = -3e-7f; blk[5] = 0.2f; blk[6] = 0.979796f;
         door[0] = 0.01f;
         bc[0] = -0.7f; bc[1] = 0.f; bc[2] = 0.08f; hb[0] = 0.5f; hb[1] = 0.45f; hb[2] = 0.08f;
+        for (int i = 0; i < 3; i++) { kc[i] = bc[i]; kc[3 + i] = hb[i]; kc[18 + i] = 0.015f; }
     }
     __syncthreads();
     int n = 0;
@@ -38,9 +39,9 @@ __global__ void __launch_bounds__(64, 2) k(int cas, long long* cyc, float* outp,
     t1 = wv::cycles();
     for (int it = 0; it < 20; it++) {
         if (l == 0) {
-            if (cas == 0) n = pmg::cyl_redo64<-1>(0, pmg::BODY_STATIC, -1, q9, blk, blk, door, bc, hb, 0.03f, 0.01f, out, W);
+            if (cas == 0) n = pmg::cyl_redo64<-1>(0, pmg::BODY_STATIC, -1, q9, blk, door, kc, 0.03f, 0.01f, out, W);
             if (cas == 2) pmg::fk64_link(q9, pmg::BODY_GBASE, p, R);
-            if (cas == 1) n = pmg::cyl_redo64<1>(pmg::BODY_GBASE, pmg::BODY_STATIC, 1, q9, blk, blk, door, bc, hb, 0.05f, 0.02f, out, W);
+            if (cas == 1) n = pmg::cyl_redo64<1>(pmg::BODY_GBASE, pmg::BODY_STATIC, 1, q9, blk, door, kc, 0.05f, 0.02f, out, W);
         }
         if (l == 0 && cas == 2) q9[0] += (float)(1e-9 * p[0] * R[4]);
         wv::lds_sync();
