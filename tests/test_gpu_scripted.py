@@ -68,7 +68,7 @@ def test_device_solves_the_task_with_the_scripted_policy(built, name):
 TEACHER = {
     'pick_and_place': ({}, 60, {'tip_pos': 1e-4, 'block_pos': 3e-4, 'q_arm': 2e-4}),                 # 0 / 0 / 0 everywhere
     'push': ({}, 300, {'tip_pos': 2e-5, 'block_pos': 1e-4, 'q_arm': 5e-5}),                         # tip 2 / 0.5 / 5, block 5 / 3 / 33, q_arm 2 / 2.5 / 10
-    'slide': ({}, 60, {'tip_pos': 2e-5, 'block_pos': 1e-4, 'q_arm': 5e-5}),                         # round 5: tip 0 / 0, block 15 / 8, q_arm 3 / 0.5
+    'slide': ({}, 60, {'tip_pos': 2e-5, 'block_pos': 1e-4, 'q_arm': 5e-5}),                         # round 5: tip 0 / 0, block 15 / 8, q_arm 3 / 0.5 (device / floor)
     'block_stack': ({'num_block': 4}, 340, {'tip_pos': 1e-4, 'block_pos': 2e-4, 'q_arm': 1e-4}),    # 1 / 0 / 2, 2 / 0 / 11, 2 / 0 / 8
     'block_rearrange': ({'num_block': 2}, 400, {'tip_pos': 5e-5, 'block_pos': 5e-4, 'q_arm': 1e-4}),  # 10 / 6.5 / 16, 62 / 52 / 147, 33 / 24 / 142
     'chest_push': ({'num_block': 1}, 360, {'tip_pos': 5e-5, 'block_pos': 5e-4, 'q_arm': 2e-4, 'door_q': 2e-5}),   # p99 measured 1.3e-5 / 2.4e-4 / 6.8e-5 / 2.7e-6 (the floor's: 1.2e-5 / 2.4e-4 / 6.3e-5 / 2.6e-6); counts: ABOVE_FLOOR
@@ -76,13 +76,12 @@ TEACHER = {
 }
 # Where the device does NOT stay within twice the chaos floor + 3.  Round 4 listed slide and chest_push here with caps of 40 / 20
 # and 700 / 1500 / 250 -- as many gross steps as the float32 build of the ORACLE (217 / 493 / 119 against a floor of 2 / 24 / 0).
-# Round 5 found the mechanism in the cylinder narrowphase (tolerance tests on coordinates recomputed in float32,
-# sqrt(1 - cos^2) for a sine, cosine thresholds at 1 mrad) and made those predicates float32-robust: measured now
-# (profiles/r05_chaos_floor.txt, device / floor): slide block 15 / 8, q_arm 3 / 0.5 -- inside the bar, no longer listed;
-# chest_push tip 10 / 1, q_arm 48 / 24, door 4 / 0, block 37 / 35.  What is left needs float64 from the forward kinematics
-# through the narrowphase (measured on the float32 oracle: both together reach the floor, neither alone moves the count):
-# (task, quantity) -> cap on the count of gross steps out of N x T = 92 160 env-steps, the measurement x 1.2.
-ABOVE_FLOOR = {('chest_push', 'tip_pos'): 12, ('chest_push', 'q_arm'): 58, ('chest_push', 'door_q'): 5}
+# Round 5: float32-robust predicates in the cylinder narrowphase (217 / 493 / 119 -> 10 / 48 / 4), then the double
+# repeat of cylinder pairs whose closest-feature direction comes from a gap under 20 um (cyl_redo64).  Measured, device / floor
+# (profiles/r05_chaos_floor.txt): slide block 15 / 8, q_arm 3 / 0.5; chest_push tip 7 / 1, q_arm 35 / 24, door 3 / 0, block
+# 38 / 35 -- everything inside the bar but ONE count, two steps over it: (task, quantity) -> cap, the measurement x 1.3.  (With
+# the repeat in every kernel and on every ambiguity the device measured 1 / 22 / 0: the floor, for 8-30 % of throughput.)
+ABOVE_FLOOR = {('chest_push', 'tip_pos'): 9}
 
 
 @pytest.mark.parametrize('task', sorted(TEACHER))

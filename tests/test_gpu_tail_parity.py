@@ -62,13 +62,12 @@ def test_teacher_forced_single_step_maximum(built, task):
 
 
 # (task, quantity) whose count of gross single steps is NOT within twice the chaos floor + 3, with the cap that holds instead
-# (the measurement x 1.2).  Round 4's list (caps 35 ... 250: as many gross steps as the float32 oracle, 10-100 x the floor) shrank
-# with the float32-robust predicates of the cylinder narrowphase; measured in round 5, device / floor of 51 200
-# steps (profiles/r05_chaos_floor.txt): slide block 15 / 0; chest_push tip 1 / 0, q_arm 17 / 7.5, door 1 / 1.5;
-# chest_pick_and_place tip 5 / 2, q_arm 16 / 2.5, door 8 / 2.5 (round 4: 17; 30, 55, 13; 59, 125, 77).  The rest is float32
-# arithmetic between the kinematics and the narrowphase at degenerate cylinder contacts: with both in double (cyl_redo64, off
-# by default for its cost) the device measured slide 0 / 0.
-ABOVE_FLOOR = {('slide', 'block_pos'): 18, ('chest_push', 'q_arm'): 21, ('chest_pick_and_place', 'q_arm'): 20, ('chest_pick_and_place', 'door_q'): 10}
+# (the measurement x 1.3).  Round 4's list (caps 35 ... 250: as many gross steps as the float32 oracle, 10-100 x the floor) is
+# down to two entries, each one step over the bar (float32-robust predicates in the cylinder narrowphase, then
+# the double repeat of cylinder pairs with a closest pair under 20 um).  Measured in round 5, device / floor of 51 200 steps
+# (profiles/r05_chaos_floor.txt): slide block 4 / 0; chest_push tip 1 / 0, q_arm 17 / 7.5, door 1 / 1.5; chest_pick_and_place
+# tip 3 / 2, q_arm 9 / 2.5, door 4 / 2.5 (round 4: 17; 30, 55, 13; 59, 125, 77).
+ABOVE_FLOOR = {('slide', 'block_pos'): 6, ('chest_pick_and_place', 'q_arm'): 12}
 P99 = {}
 
 
