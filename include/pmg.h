@@ -60,9 +60,11 @@ enum {
     PMG_BUF_SCHED = 9,   /* [4 + 3N + 3 ceil(N / 1024)] int32 launch schedule of the last step (diagnostics): n_prone, n_free,
                             prone list [N], free list [N], n_redo, redo list [N], then the two-pass plan's per-workgroup class
                             counts and its promotion flag -- see DESIGN.md "launch-order plan" */
-    PMG_BUF_ENV_CYCLES = 10 /* [N, 2] int32 (diagnostics; only when the handle was created with PMG_ENV_CYCLES=1 in the
-                            environment, PMG_E_INVALID otherwise): shader cycles / 64 the env's wavefront spent in its last
-                            step, and the largest contact count any of that step's substeps saw (envs with free objects) */
+    PMG_BUF_ENV_CYCLES = 10 /* [N, 2] int32: shader cycles / 64 the env's wavefront spent in its last step, and the largest contact
+                            count any of that step's substeps saw (envs with free objects).  Kept when the handle was created with
+                            PMG_ENV_CYCLES=1 in the environment (diagnostics) AND whenever the longest-first order of the fast-path
+                            list is on (block_stack and the chest tasks from 4096 envs, PMG_LPT_CYCLES; the plan's predictor: 8 B per
+                            env written every step); PMG_E_INVALID otherwise */
 };
 
 /* POD configuration; mirrors the kwargs of pmg.make_env (P/__init__.py:4-11)

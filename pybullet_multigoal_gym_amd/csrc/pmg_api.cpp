@@ -586,7 +586,7 @@ int pmg_device_ptr(pmg_env* e, int which, void** d_ptr)
     case PMG_BUF_STATE: *d_ptr = e->P.hot; return PMG_OK;
     case PMG_BUF_SCHED: *d_ptr = e->P.sched; return PMG_OK;
     case PMG_BUF_ENV_CYCLES:
-        if (!e->P.env_cycles) return fail(e, PMG_E_INVALID, "pmg_device_ptr: PMG_BUF_ENV_CYCLES needs PMG_ENV_CYCLES=1 in the environment at pmg_create");
+        if (!e->P.env_cycles) return fail(e, PMG_E_INVALID, "pmg_device_ptr: PMG_BUF_ENV_CYCLES is kept only with PMG_ENV_CYCLES=1 in the environment at pmg_create, or with the longest-first order on (PMG_LPT_CYCLES)");
         *d_ptr = e->P.env_cycles; return PMG_OK;
     default: return fail(e, PMG_E_INVALID, "pmg_device_ptr: buffer %d is not a device buffer (use PMG_BUF_PACKED + pmg_dims offsets)", which);
     }
