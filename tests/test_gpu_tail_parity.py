@@ -93,9 +93,10 @@ def test_teacher_forced_outliers_against_the_chaos_floor(built, task):
         assert d['p50'] <= 2e-6, (task, name, d)
 
 
-# whole episodes: (p99 of the object-position error, envs beyond 1e-3, differing flags) where twice the chaos floor does not hold
-# chest_push-2: p99 1.3e-2 against the floor's 1.7e-3, 42 envs of 1024 beyond 1e-3 against 15 (round 4; the float32 oracle: 2.1e-2 / 50)
-EPISODE_ABOVE_FLOOR = {'chest_push': (2e-2, 60, 205)}
+# whole episodes: (p99 of the object-position error, envs beyond 1e-3, differing flags) where twice the chaos floor does not hold.
+# Round 4 listed chest_push-2 (p99 1.3e-2 against the floor's 1.7e-3, 42 envs of 1024 beyond 1e-3 against 15: caps 2e-2 / 60 /
+# 205); round 5 measures 3.1e-3 / 25 / 0 against 1.7e-3 / 14 / 0 -- inside the bar: the list is empty.
+EPISODE_ABOVE_FLOOR = {}
 
 
 @pytest.mark.parametrize('task', ['push', 'pick_and_place', 'block_stack', 'block_rearrange', 'chest_push'])
