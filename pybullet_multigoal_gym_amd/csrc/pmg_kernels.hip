@@ -262,7 +262,10 @@ constexpr int LIST0_THREADS = PMG_LIST_TWO_WAVES ? 128 : 64;
 /* ... except on the lid task (chest_pick_and_place, CYL == 3): a quarter of its batch is on list 0, the step is bound by the
  * wavefront slots, not by one chain, and the helper wavefronts cost more slots than they shorten chains (0.580 -> 0.609 M
  * without them; chest_push neutral, the block tasks lose 1 %: they keep theirs) */
-constexpr bool list_two_waves(int list, int cyl) { return list == 0 && PMG_LIST_TWO_WAVES != 0 && cyl != 3; }
+#ifndef PMG_LID_TWO_WAVES
+#define PMG_LID_TWO_WAVES 0
+#endif
+constexpr bool list_two_waves(int list, int cyl) { return list == 0 && PMG_LIST_TWO_WAVES != 0 && (cyl != 3 || PMG_LID_TWO_WAVES != 0); }
 template <int NB, int MAXC, int LIST, int CYL = 0>
 __global__ void __launch_bounds__(list_two_waves(LIST, CYL) ? 128 : 64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
