@@ -74,13 +74,13 @@ def test_spaces_and_bullet_call_counts(built, emu_library, path):
 
 
 # float32 device vs the float64 physics under the fixtures, over WHOLE episodes: resets / goals / curricula / sub-goals to
-# 2e-5 (positions of a reset are IK solutions); trajectories at BASELINE.json's 1e-3 (reach: 2e-5), velocity columns 5e-3
-# (Bullet's solver stops iterating at 3e-4 m/s of residual).  FIXED bars for every session.  Rounds 3-4 relaxed seven
+# 2e-5 (positions of a reset are IK solutions); trajectories 2e-4 (reach: 2e-5) and the velocity columns at BASELINE.json's
+# 1e-3 (Bullet's solver stops iterating at 3e-4 m/s of residual; rounds 3-4: 1e-3 / 5e-3).  FIXED bars for every session.  Rounds 3-4 relaxed seven
 # sessions (`RELAXED`: up to 5e-3 / 2e-2) wherever the float32 build of the ORACLE strayed from the fixture -- the device
 # measures 3e-5 (positions) and 4.5e-4 (velocity columns) on those very sessions (round 5, gpurun_out/r05h), so the list and
 # the float32-oracle yardstick are gone.
 GPU_BARS = {'reach': dict(tol_traj=2e-5, tol_vel=1e-3)}     # 2.5e-7; velocities 2.2e-4 with joint control (fingers on the table)
-GPU_DEFAULT = dict(tol_traj=1e-3, tol_vel=5e-3)
+GPU_DEFAULT = dict(tol_traj=2e-4, tol_vel=1e-3)   # measured over all 36 sessions, whole episodes (round 5): positions <= 3.0e-5, velocity columns <= 5.4e-4
 
 
 def _replay_whole_episodes(path, library):
