@@ -500,6 +500,57 @@ def test_rccl_single_rank_allgather_and_kernel_timer(built):
     env.close()
 
 
+def test_rccl_single_rank_overlapped_allgather_on_the_device(built):
+    """pmg_comm_overlap on the real runtime (one rank through RCCL): 12 steps with random actions, the all-gather of every step
+    enqueued on the communication stream and NOT waited for before the next two steps are enqueued; every gathered table
+    must hold exactly the rows its step left (read back from the double-buffered row buffer right behind the step), the
+    row buffer must alternate, and the comm events count every all-gather."""
+    N, T = 1024, 12
+    env = pmg.make_env(task='push', num_envs=N, seed=1, seed_stride=1, max_episode_steps=5)
+    h = env.handle
+    h.comm_init(0, 1, h.comm_unique_id())
+    h.comm_overlap(True)
+    env.reset()
+    S = env.dims.packed_dim
+    rs = np.random.RandomState(3)
+    acts = [h.device_alloc(N * 3 * 4) for _ in range(T)]
+    for a in acts:
+        h.upload(a, rs.uniform(-1, 1, (N, 3)).astype(np.float32))
+    tables = [h.device_alloc(N * S * 4) for _ in range(T)]       # one table per step: all of them are checked at the end
+    rows_ptr = []
+    h.timing_reset()
+    for t in range(T):
+        h.step_device(acts[t])
+        h.reset_done_device()
+        rows_ptr.append(h.device_ptr())
+        h.allgather_packed_async(tables[t])
+    h.allgather_wait(host=True)
+    h.sync()
+    assert len(set(rows_ptr)) == 2 and all(rows_ptr[t] != rows_ptr[t + 1] for t in range(T - 1))
+    assert h.comm_timing()[2] == T
+    # replay the same steps without the collective: the rows of every step, to compare the tables with
+    ref = pmg.make_env(task='push', num_envs=N, seed=1, seed_stride=1, max_episode_steps=5)
+    ref.reset()
+    want = np.zeros((N, S), np.float32)
+    got = np.zeros((N, S), np.float32)
+    for t in range(T):
+        a = np.zeros((N, 3), np.float32)
+        h.download(a, acts[t])
+        aa = ref.handle.device_alloc(N * 3 * 4)
+        ref.handle.upload(aa, a)
+        ref.handle.step_device(aa)
+        ref.handle.reset_done_device()
+        ref.handle.sync()
+        ref.handle.download(want, ref.handle.device_ptr())
+        ref.handle.device_free(aa)
+        h.download(got, tables[t])
+        assert np.array_equal(got, want), (t, np.abs(got - want).max())
+    for p in acts + tables:
+        h.device_free(p)
+    ref.close()
+    env.close()
+
+
 @pytest.mark.parametrize('task,N,kw', [('pick_and_place', 8192, {'binary_reward': False}),      # BASELINE.json configs[3]: dense ...
                                        ('pick_and_place', 8192, {'binary_reward': True}),       # ... and binary
                                        ('block_stack', 4096, {'num_block': 4}),                  # configs[4]
