@@ -12,7 +12,10 @@ import oracle_lib  # noqa: E402
 import teacher_forced as TF  # noqa: E402
 
 TASKS = {'slide': {}, 'chest_push': {'num_block': 2}, 'chest_pick_and_place': {'num_block': 2}, 'push': {}, 'block_stack': {'num_block': 4}}
+only = sys.argv[1:]
 for task, kw in TASKS.items():
+    if only and task not in only:
+        continue
     r = TF.run(task, 4096, 50, kw, device=True, threads=oracle_lib.usable_threads(), perturb=2)
     row = {'task': task, 'N': 4096, 'T': 50, 'kw': kw, 'quantities': {}}
     for q in ('tip_pos', 'block_pos', 'q_arm', 'door_q'):

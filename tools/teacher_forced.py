@@ -83,6 +83,9 @@ def run(task, N=1024, T=50, kw=None, device=True, threads=16, seed=12345, lib=No
     gross_any = {}
     if device:
         import pybullet_multigoal_gym_amd as pmg
+        if lib is None and os.environ.get('PMG_TF_LIB'):           # (kernel A/B: another build of the library, tools/ab.sh style)
+            from pybullet_multigoal_gym_amd._lib import PmgLibrary
+            lib = PmgLibrary(os.environ['PMG_TF_LIB'])
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             dev = pmg.make_env(task=task, num_envs=N, seed=0, seed_stride=1, _library=lib, **kw)
