@@ -135,6 +135,14 @@ static const double JDAMP[NJ] = PMG_JDAMP;
 static const int ROW_ORDER[18] = PMG_ROW_ORDER;
 static const double FINGER_HALF[3] = PMG_FINGER_HALF;
 static const double TABLE_HALF[3] = PMG_TABLE_HALF;
+/* The robot URDF's base link (iiwa14_parallel_jaw.urdf:37-58): a 5 x 5 x 0.002 m box under link_0 at the world origin, lateral
+ * friction 1 -- the floor.  An object knocked off the table lands on it (z = 0.001 + its half height) instead of falling for
+ * the rest of the episode.  One static pair per object serves both: below PLANE_SWITCH_Z (the object's bounding sphere -- cube
+ * 0.026, puck 0.0317 -- can reach the floor; it is then 8.6 cm under the table top and can touch the table at its side walls only)
+ * the static partner of the object is the floor, above it the table.  Build choice, documented in DESIGN.md: an object that
+ * already lies on the floor does not collide with the table's side walls. */
+static const double PLANE_HALF[3] = PMG_PLANE_HALF;
+#define PLANE_SWITCH_Z 0.04
 static const double BLOCK_HALF[3] = PMG_BLOCK_HALF;
 static const double BLOCK_INERTIA[3] = PMG_BLOCK_INERTIA;
 
@@ -1630,10 +1638,12 @@ static int collide(const pmgo_env* e, const World* w, const Kin* k, Contact* out
         o->a = (A); o->b = (B); o->mu = (MU); o->dist = cp[c_].dist;                    \
         v3cpy(o->pa, cp[c_].pa); v3cpy(o->pb, cp[c_].pb); v3cpy(o->n, cp[c_].n);        \
     }
-    /* object (A) x table (B) */
+    /* object (A) x table (B); an object that has left the table: x the floor of the robot URDF (PLANE_SWITCH_Z above) */
     for (int b = 0; b < e->nb; b++) {
-        int n_ = obj_vs_box(e, w, (const real (*)[9])Rb, b, 1, e->table_c, I3, e->table_h, cp);
-        EMIT(b, BODY_STATIC, e->obj_mu * e->table_mu)
+        const int on_floor = w->blk[b].pos[2] < (real)PLANE_SWITCH_Z;
+        const real plane_c[3] = {0, 0, 0}, plane_h[3] = {(real)PLANE_HALF[0], (real)PLANE_HALF[1], (real)PLANE_HALF[2]};
+        int n_ = obj_vs_box(e, w, (const real (*)[9])Rb, b, 1, on_floor ? plane_c : e->table_c, I3, on_floor ? plane_h : e->table_h, cp);
+        EMIT(b, BODY_STATIC, e->obj_mu * (on_floor ? (real)PMG_PLANE_FRICTION : e->table_mu))
     }
     /* block x block */
     for (int b = 0; b < e->nb; b++)

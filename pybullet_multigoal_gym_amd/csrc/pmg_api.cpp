@@ -448,8 +448,9 @@ void pmg_destroy(pmg_env* e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);   /* an overlapped all-gather in flight reads out2[] through e->comm */
     if (e->comm) ncclCommDestroy(e->comm);
-    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); if (e->out2[0]) { (void)hipFree(e->out2[0]); (void)hipFree(e->out2[1]); } else (void)hipFree(e->P.out); (void)hipFree(e->P.sched); if (e->P.env_cycles) (void)hipFree(e->P.env_cycles);
+    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); if (e->out2[1]) { (void)hipFree(e->out2[0]); (void)hipFree(e->out2[1]); } else (void)hipFree(e->P.out); (void)hipFree(e->P.sched); if (e->P.env_cycles) (void)hipFree(e->P.env_cycles);
     (void)hipFree(e->d_actions); (void)hipFree(e->d_mask);
     (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
     if (e->h_packed) (void)hipHostFree(e->h_packed);
@@ -488,10 +489,24 @@ int pmg_seed(pmg_env* e, uint64_t base, uint64_t stride)
     return upload_seeds(e);
 }
 
+/* Overlapped all-gather: a gather of the CURRENT row buffer may still be reading it on the communication stream (the step that
+ * wrote it was gathered, the next step has not been queued yet).  Whatever writes rows into that buffer between two steps -- a
+ * reset, set_sub_goal, the reset of nobody behind pmg_set_state -- goes behind that gather; the gathered table of step t then
+ * holds step t's rows and nothing of the reset that followed it (bench.py --lockstep resets right behind the gather). */
+static int rows_writer_waits_for_gather(pmg_env* e)
+{
+    if (e->overlap && e->gpending[e->out_phase]) {
+        HIP_TRY(e, hipStreamWaitEvent(e->stream, e->ev_gdone[e->out_phase], 0));
+        e->gpending[e->out_phase] = false;
+    }
+    return PMG_OK;
+}
+
 int pmg_reset_device(pmg_env* e, const uint8_t* d_mask)
 {
     if (!e) return PMG_E_INVALID;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (int rc = rows_writer_waits_for_gather(e)) return rc;
     HIP_TRY(e, pmg_launch_reset(e->P, d_mask, e->stream));
     if (!d_mask) e->ever_reset = true;
     return PMG_OK;
@@ -502,6 +517,7 @@ int pmg_reset_done_device(pmg_env* e)
     if (!e) return PMG_E_INVALID;
     if (!e->ever_reset) return fail(e, PMG_E_STATE, "pmg_reset_done_device: reset() must be called (for all envs) first");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (int rc = rows_writer_waits_for_gather(e)) return rc;
     HIP_TRY(e, pmg_launch_reset(e->P, nullptr, e->stream, 1));
     return PMG_OK;
 }
@@ -694,6 +710,7 @@ int pmg_set_state(pmg_env* e, const float* state)
     e->ever_reset = true;
     /* the packed rows still show the previous state: a reset of NOBODY re-derives every env's observation and goal */
     HIP_TRY(e, hipMemsetAsync(e->d_mask, 0, N, e->stream));
+    if (int rc = rows_writer_waits_for_gather(e)) return rc;
     HIP_TRY(e, pmg_launch_reset(e->P, e->d_mask, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return PMG_OK;
@@ -748,6 +765,7 @@ int pmg_set_sub_goal(pmg_env* e, const uint8_t* mask, int32_t sub_goal_ind)
         HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, (size_t)e->dims.num_envs, hipMemcpyHostToDevice, e->stream));
         dm = e->d_mask;
     }
+    if (int rc = rows_writer_waits_for_gather(e)) return rc;
     HIP_TRY(e, pmg_launch_sub_goal(e->P, dm, sub_goal_ind < 0 ? steps - 1 : sub_goal_ind, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return PMG_OK;
@@ -833,16 +851,30 @@ int pmg_comm_overlap(pmg_env* e, int32_t enabled)
         e->overlap = false;       /* (the rows stay where the last step wrote them: P.out keeps pointing at that buffer) */
         return PMG_OK;
     }
-    if (!e->out2[0]) {
+    if (!(e->out2[1] && e->comm_stream)) {
+        /* everything into locals first: a failure half-way must not leave a handle that looks initialised (out2[0] set, the second
+         * buffer / the stream / the events null) to the next call */
         const size_t bytes = (size_t)e->dims.num_envs * e->dims.packed_dim * sizeof(float);
-        e->out2[0] = e->P.out;
-        if (hipMalloc((void**)&e->out2[1], bytes) != hipSuccess) return fail(e, PMG_E_NOMEM, "pmg_comm_overlap: hipMalloc(%zu) failed", bytes);
-        HIP_TRY(e, hipMemcpyAsync(e->out2[1], e->out2[0], bytes, hipMemcpyDeviceToDevice, e->stream));
-        HIP_TRY(e, hipStreamCreateWithFlags(&e->comm_stream, hipStreamNonBlocking));
-        for (int b = 0; b < 2; b++) {
-            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_rows[b], hipEventDisableTiming));
-            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_gdone[b], hipEventDisableTiming));
+        float* second = nullptr;
+        hipStream_t cs = nullptr;
+        hipEvent_t rows[2] = {nullptr, nullptr}, gdone[2] = {nullptr, nullptr};
+        hipError_t rc = hipMalloc((void**)&second, bytes);
+        if (rc == hipSuccess) rc = hipMemcpyAsync(second, e->P.out, bytes, hipMemcpyDeviceToDevice, e->stream);
+        if (rc == hipSuccess) rc = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        for (int b = 0; b < 2 && rc == hipSuccess; b++) {
+            rc = hipEventCreateWithFlags(&rows[b], hipEventDisableTiming);
+            if (rc == hipSuccess) rc = hipEventCreateWithFlags(&gdone[b], hipEventDisableTiming);
         }
+        if (rc != hipSuccess) {
+            (void)hipStreamSynchronize(e->stream);
+            for (int b = 0; b < 2; b++) { if (rows[b]) (void)hipEventDestroy(rows[b]); if (gdone[b]) (void)hipEventDestroy(gdone[b]); }
+            if (cs) (void)hipStreamDestroy(cs);
+            if (second) (void)hipFree(second);
+            return fail(e, second ? PMG_E_DEVICE : PMG_E_NOMEM, "pmg_comm_overlap: %s", hipGetErrorString(rc));
+        }
+        e->out2[0] = e->P.out; e->out2[1] = second;
+        e->comm_stream = cs;
+        for (int b = 0; b < 2; b++) { e->ev_rows[b] = rows[b]; e->ev_gdone[b] = gdone[b]; }
         e->out_phase = 0;
     }
     e->overlap = true;

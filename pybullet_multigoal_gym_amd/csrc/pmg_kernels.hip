@@ -266,11 +266,18 @@ constexpr int LIST0_THREADS = PMG_LIST_TWO_WAVES ? 128 : 64;
 #define PMG_LID_TWO_WAVES 0
 #endif
 constexpr bool list_two_waves(int list, int cyl) { return list == 0 && PMG_LIST_TWO_WAVES != 0 && (cyl != 3 || PMG_LID_TWO_WAVES != 0); }
+/* ... and slide's list 0 with a THIRD one, which repeats the finger x puck pairs in double beside the helper's float narrowphase
+ * (pmg::SpecLds; the rule that brings slide's single steps to the chaos floor, off the critical path) */
+constexpr bool list_spec_wave(int list, int cyl) { return list_two_waves(list, cyl) && cyl == 1 && PMG_CYL_SPEC != 0 && PMG_CYL_PUSH_ALL != 0 && PMG_CYL_REDO64 != 0; }
+constexpr int list_threads(int list, int cyl) { return list_spec_wave(list, cyl) ? 192 : (list_two_waves(list, cyl) ? 128 : 64); }
+template <bool ON> struct SpecStore { __device__ static __forceinline__ pmg::SpecLds* get() { return nullptr; } };
+template <> struct SpecStore<true> { __device__ static __forceinline__ pmg::SpecLds* get() { __shared__ pmg::SpecLds s; return &s; } };
 template <int NB, int MAXC, int LIST, int CYL = 0>
-__global__ void __launch_bounds__(list_two_waves(LIST, CYL) ? 128 : 64, PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
+__global__ void __launch_bounds__(list_threads(LIST, CYL), PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmg::ContactLds<NB, MAXC> L;
     __shared__ pmg::LaneTabStore lcs;
+    pmg::SpecLds* sp = SpecStore<list_spec_wave(LIST, CYL)>::get();
     const int b = (int)blockIdx.x;
     if (b >= P.sched[LIST]) return;
     /* issue priority for the wavefronts that are the long pole of the step: list 0 of the multi-block / chest tasks
@@ -279,7 +286,7 @@ __global__ void __launch_bounds__(list_two_waves(LIST, CYL) ? 128 : 64, PMG_WAVE
      * with it and do not promote); PMG_LIST0_PRIO overrides (tools/prio_exp.sh) */
     if (LIST == 0) wv::set_priority(P.list0_prio >= 0 ? P.list0_prio : ((NB > 1 || *pmg::plan_promoted(P)) ? 1 : 0));
     const int env = P.sched[2 + LIST * P.n_envs + b];
-    const bool ok = pmg::step_env_core<NB, MAXC, CYL, list_two_waves(LIST, CYL)>(P, actions, env, L, lcs, true);
+    const bool ok = pmg::step_env_core<NB, MAXC, CYL, list_two_waves(LIST, CYL), list_spec_wave(LIST, CYL)>(P, actions, env, L, lcs, true, sp);
     if (!ok && threadIdx.x == 0) {
         int* redo = P.sched + 2 + 2 * P.n_envs;
         int slot = atomicAdd(redo, 1);
@@ -367,7 +374,7 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         const int groups = (P.n_envs + 3) / 4;
         hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
         if (P.task == PMG_TASK_SLIDE) {
-            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
+            hipLaunchKernelGGL((pmg_k_step_list<1, 24, 0, true>), dim3(P.n_envs), dim3(list_threads(0, 1)), 0, s0, P, d_actions);
             if (!list0_first) PMG_FJ(hipEventRecord(ev_join, side));
             hipLaunchKernelGGL((pmg_k_step_obj4<true>), dim3(groups), dim3(OBJ4_THREADS), 0, s1, P, d_actions);
             if (list0_first) PMG_FJ(hipEventRecord(ev_join, side));

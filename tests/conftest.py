@@ -44,6 +44,21 @@ def emu_library_small_rowspace(built, tmp_path_factory):
 
 
 @pytest.fixture(scope='session')
+def emu_library_serial_repeat(built, tmp_path_factory):
+    """The emulator build WITHOUT the speculative third wavefront (-DPMG_CYL_SPEC=0): slide's list-0 kernel repeats the
+    finger x puck pairs in double serially on the helper wavefront, round 5's layout."""
+    import subprocess
+    from pybullet_multigoal_gym_amd._lib import PmgLibrary
+    out = str(tmp_path_factory.mktemp('emu') / 'libpmg_emu_serial.so')
+    emu = os.path.join(ROOT, 'tests', 'emu')
+    src = os.path.join(ROOT, 'pybullet_multigoal_gym_amd', 'csrc')
+    subprocess.check_call(['g++', '-O2', '-fPIC', '-std=c++17', '-I' + emu, '-I' + src, '-Wno-unknown-pragmas', '-DPMG_CYL_SPEC=0',
+                           '-shared', '-o', out, os.path.join(emu, 'hip_emu.cpp'), os.path.join(emu, 'pmg_probe.cpp'),
+                           os.path.join(src, 'pmg_api.cpp'), '-x', 'c++', os.path.join(src, 'pmg_kernels.hip'), '-lrt'])
+    return PmgLibrary(out)
+
+
+@pytest.fixture(scope='session')
 def hip_library(built):
     from pybullet_multigoal_gym_amd._lib import default_library
     return default_library()

@@ -7,7 +7,8 @@ emu_dim3 threadIdx, blockIdx, blockDim, gridDim;
 float emu_xf[16 * 64 * 16];
 long long pmge_face_clip_calls = 0;
 extern "C" long long pmge_face_clip_count() { return pmge_face_clip_calls; }
-long long pmge_cyl_contact_calls = 0, pmge_cyl_redo_calls = 0;
+long long pmge_cyl_contact_calls = 0, pmge_cyl_redo_calls = 0, pmge_cyl_spec_taken_n = 0;
+extern "C" long long pmge_cyl_spec_taken() { return pmge_cyl_spec_taken_n; }
 extern "C" long long pmge_cyl_contact_count() { return pmge_cyl_contact_calls; }
 extern "C" long long pmge_cyl_redo_count() { return pmge_cyl_redo_calls; }
 

@@ -47,7 +47,7 @@ void emu_block_barrier();   /* workgroup-level: every live thread arrives */
 /* exchange buffer for cross-lane primitives */
 extern float emu_xf[16 * 64 * 16]; /* [wave][slot][lane] */
 extern long long pmge_face_clip_calls;   /* calls of box_face_clip (pmg_contact_body.inc) since load */
-extern long long pmge_cyl_contact_calls, pmge_cyl_redo_calls;   /* cylinder pairs found in contact by the float pass / repeated in double (cyl_redo64) */
+extern long long pmge_cyl_contact_calls, pmge_cyl_redo_calls, pmge_cyl_spec_taken_n;   /* cylinder pairs found in contact by the float pass / repeated in double (cyl_redo64) */
 
 namespace emu {
 void launch(int grid, int block, const std::function<void()>& body);

@@ -54,7 +54,7 @@ def _worker(rank, world, port, total, ret):
     dist.destroy_process_group()
 
 
-def _overlap_worker(rank, world, port, total, steps, broken):
+def _overlap_worker(rank, world, port, total, steps, broken, reset_behind_gather=False):
     """Two ranks, overlapped all-gather on the emulator with a LAZY communication stream (the all-gather runs as late as its
     recorded dependencies allow): every gathered table must hold the rows of ITS step from every rank."""
     sys.path.insert(0, ROOT)
@@ -82,7 +82,8 @@ def _overlap_worker(rank, world, port, total, steps, broken):
         a = rs.uniform(-1, 1, (total, 3)).astype(np.float32)[start:stop]
         h.upload(acts, np.ascontiguousarray(a))
         h.step_device(acts)
-        h.reset_done_device()                                   # TimeLimit resets of the step belong to its rows
+        if not reset_behind_gather:
+            h.reset_done_device()                               # TimeLimit resets of the step belong to its rows
         rows = np.empty((n, S), np.float32)
         h.download(rows, h.device_ptr())                       # the rows of THIS step (the buffer of the last step)
         ptrs.add(h.device_ptr())
@@ -97,6 +98,11 @@ def _overlap_worker(rank, world, port, total, steps, broken):
                 got.append(g)
             continue
         h.allgather_packed_async(tables[t & 1])               # nothing waits for it here: step t + 1 is enqueued right behind
+        if reset_behind_gather:
+            # bench.py --lockstep's order: the reset of an episode's start is issued right BEHIND the step's (lazy, still
+            # pending) all-gather and writes the row buffer the gather reads -- the library must put it behind the gather,
+            # or the gathered table of step t holds post-reset rows
+            h.reset_device(None)
     if not broken:
         h.allgather_wait(host=True)
         assert len(ptrs) == 2                                   # the rows alternate between two buffers
@@ -124,6 +130,14 @@ def _overlap_worker(rank, world, port, total, steps, broken):
         assert bad > 0, 'the late single-buffer gather went unnoticed: the check has no teeth'
     else:
         assert bad == 0, 'an overlapped all-gather delivered rows of another step'
+
+
+def test_reset_issued_behind_an_overlapped_allgather_does_not_reach_its_rows(built):
+    """Order step, gather_async, reset(everybody), step (bench.py --lockstep at N > 1): the reset writes the row
+    buffer an in-flight all-gather reads; pmg_reset* wait for that gather on the step's stream first."""
+    import torch.multiprocessing as mp
+    port = 35000 + os.getpid() % 2000
+    mp.spawn(_overlap_worker, args=(2, port, 4, 5, False, True), nprocs=2, join=True)
 
 
 @pytest.mark.parametrize('broken', [False, True])

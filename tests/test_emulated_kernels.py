@@ -103,6 +103,58 @@ def test_emulated_slide_puck_matches_oracle(emu_library):
     env.close()
 
 
+@pytest.mark.parametrize('task,kw,rest_z', [('push', {}, 0.016), ('slide', {}, 0.011), ('block_stack', {'num_block': 2}, 0.016)])
+def test_emulated_object_off_the_table_lands_on_the_floor(emu_library, task, kw, rest_z):
+    """The robot URDF's base plane (iiwa14_parallel_jaw.urdf:37-58: 5 x 5 x 0.002 m box at the origin, friction 1): an object
+    that has left the table lands on it at z = 0.001 + its half height and stays there -- on the emulated kernels as in the
+    oracle -- instead of falling for the rest of the episode (rounds 1-5)."""
+    env, ora = _pair(emu_library, task, **kw)
+    st = ora.get_state().copy()
+    edge = (-0.70 if task == 'slide' else -0.52) + (0.5 if task == 'slide' else 0.25)       # the table's +x side wall
+    st[0, 64:67] = [edge + 0.04, 0.02, 0.17]
+    st[0, 67:71] = [0, 0, 0, 1]; st[0, 71:77] = 0
+    env.set_state(st), ora.set_state(st)
+    A = env.dims.action_dim
+    for t in range(4):
+        a = np.zeros((1, A), np.float32)
+        o, r, d, _ = env.step(a)
+        oo, ro, do, _ = ora.step(a)
+    se, so = env.get_state()[0], ora.get_state()[0]
+    assert abs(so[66] - rest_z) < 2e-4 and abs(se[66] - rest_z) < 2e-4, (se[64:67], so[64:67])   # at rest on the floor, both
+    assert np.abs(se[64:71] - so[64:71]).max() < 5e-5 and np.abs(se[71:77] - so[71:77]).max() < 2e-3
+    assert np.abs(se[:9] - so[:9]).max() < 2e-5
+    env.close()
+
+
+def test_speculative_double_repeat_is_bit_identical_to_the_serial_repeat(emu_library, emu_library_serial_repeat):
+    """slide, the fingers pushing the puck (list 0: three wavefronts per workgroup -- env, float narrowphase, the finger x puck
+    pairs in double beside it): states and outputs EQUAL to the build that repeats those pairs serially behind the float pass
+    (round 5's PMG_CYL_PUSH_ALL layout), and the double results are really taken (the emulator counts them)."""
+    import ctypes as C
+    N = 3
+    envs = [pmg.make_env(task='slide', num_envs=N, seed=3, seed_stride=1, _library=lib) for lib in (emu_library, emu_library_serial_repeat)]
+    for e in envs:
+        e.reset()
+    st = envs[0].get_state().copy()
+    st[:, 64] = -0.52 + np.float32([0.0, 0.003, -0.002]); st[:, 65] = 0.045 + np.float32([0.0, -0.002, 0.003]); st[:, 66] = 0.170
+    st[:, 67:71] = [0, 0, 0, 1]; st[:, 71:77] = 0
+    for e in envs:
+        e.set_state(st)
+    counter = C.CDLL(emu_library.path).pmge_cyl_spec_taken
+    counter.restype = C.c_longlong
+    before = counter()
+    for a in ([0, 1, 0], [0, 1, 0], [0.3, 1, 0]):
+        a = np.tile(np.float32(a), (N, 1))
+        outs = [e.step(a) for e in envs]
+        assert all(np.array_equal(outs[0][0][k], outs[1][0][k]) for k in outs[0][0])
+        assert np.array_equal(envs[0].get_state(), envs[1].get_state())
+        assert envs[0].handle.schedule()['prone'].size == N             # every env ran on list 0: the three-wavefront kernel
+    assert counter() - before > 50                                        # the fingers were on the puck: double results taken
+    assert (envs[0].get_state()[:, 65] > 0.06).all()
+    for e in envs:
+        e.close()
+
+
 def test_emulated_gripper_base_contact_matches_oracle(emu_library):
     """gripper-base cylinder (link 7) x block pairs: a block wedged between the open fingers against the palm."""
     env, ora = _pair(emu_library, 'pick_and_place')

@@ -72,6 +72,7 @@ def parse_robot():
         col = L.find('collision')
         ext = None
         kind = None
+        aabb = None     # collision shape's bounding box in the link frame (tools/arm_link_penetration.py)
         if col is not None:
             corg = col.find('origin')
             assert corg is None or (vec(corg.get('xyz')) == [0, 0, 0] and vec(corg.get('rpy')) == [0, 0, 0])
@@ -80,13 +81,16 @@ def parse_robot():
                 lo, hi = stl_extent(os.path.join(REF, 'robots/kuka', g.get('filename')))
                 ext = (hi - lo + 4 * MARGIN).tolist()
                 kind = 'hull'
+                aabb = [lo.tolist(), hi.tolist()]
             elif g.tag == 'box':
                 ext = vec(g.get('size'))
                 kind = 'box'
+                aabb = [[-x / 2 for x in ext], [x / 2 for x in ext]]
             elif g.tag == 'cylinder':
                 r, l = float(g.get('radius')), float(g.get('length'))
                 ext = [2 * r, 2 * r, l]
                 kind = 'cyl'
+                aabb = [[-r, -r, -l / 2], [r, r, l / 2]]
         scaling = 1.0
         fric = None
         c = L.find('contact')
@@ -99,7 +103,7 @@ def parse_robot():
             inertia = [scaling * x for x in box_inertia(mass, ext)]
         else:
             inertia = urdf_inertia  # mass-0 helper links keep the URDF diagonal
-        links[name] = dict(mass=mass, com=com, inertia=inertia, ext=ext, kind=kind, fric=fric)
+        links[name] = dict(mass=mass, com=com, inertia=inertia, ext=ext, kind=kind, fric=fric, aabb=aabb)
     joints = []
     for J in root.findall('joint'):
         o = J.find('origin')
@@ -215,6 +219,10 @@ def main():
             ext = [2 * float(g.get('radius'))] * 2 + [float(g.get('length'))]
         I = [sc * x for x in box_inertia(m, ext)] if m > 0 else [0, 0, 0]
         return dict(mass=m, ext=ext, friction=fr, inertia=I, shape=g.tag)
+    # the robot URDF's own base link (iiwa14_parallel_jaw.urdf:37-58): a 5 x 5 x 0.002 m collision box under link_0, friction 1 --
+    # the floor an object knocked off the table lands on.  The robot base sits at the world origin (robot_bases.py:39-40).
+    assert links['plane']['kind'] == 'box' and links['plane']['mass'] == 0
+    model['plane'] = dict(mass=0.0, ext=links['plane']['ext'], friction=links['plane']['fric'], inertia=[0, 0, 0], shape='box')
     model['table'] = obj('table.urdf')
     model['long_table'] = obj('long_table.urdf')
     model['block'] = obj('block.urdf')
@@ -289,7 +297,7 @@ def main():
             bl.append(dict(name=j['child'], joint=j['name'], parent=parent_idx,
                            type={'revolute': 0, 'prismatic': 1, 'fixed': 2}[j['type']],
                            xyz=j['xyz'], R=rpy_to_R(*j['rpy']).tolist(), axis=j['axis'] or [0.0, 0.0, 0.0],
-                           mass=L['mass'], com=L['com'], inertia=L['inertia'], dof=dof))
+                           mass=L['mass'], com=L['com'], inertia=L['inertia'], dof=dof, col_aabb=L['aabb']))
             walk(j['child'], idx)
     walk('plane', -1)
     names = [b['joint'] for b in bl]
@@ -379,7 +387,7 @@ def main():
     H.append('#define PMG_BL_COM ' + arr([b['com'] for b in bl]))
     H.append('#define PMG_BL_INERTIA ' + arr([b['inertia'] for b in bl]))
     H.append('#define PMG_BL_TIP 8\n#define PMG_BL_GBASE 12\n#define PMG_BL_FINGER1 13\n#define PMG_BL_TAB1 14\n#define PMG_BL_FINGER2 15\n#define PMG_BL_TAB2 16')
-    for k in ['table', 'long_table', 'block', 'puck']:
+    for k in ['plane', 'table', 'long_table', 'block', 'puck']:
         o = model[k]
         K = k.upper()
         H.append('#define PMG_%s_HALF %s' % (K, arr([x / 2 for x in o['ext']])))
