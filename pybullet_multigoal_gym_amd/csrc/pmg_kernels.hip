@@ -284,7 +284,9 @@ __global__ void __launch_bounds__(list_threads(LIST, CYL), PMG_WAVES_PER_EU) pmg
      * (block_stack-4 +2.6 %), list 0 of a one-object task when the plan moved the fingers-down class there
      * (pick_and_place 1.59 -> 1.85 M; push / slide, whose long pole is the packed fingers-down wavefront, lose 3 / 8 %
      * with it and do not promote); PMG_LIST0_PRIO overrides (tools/prio_exp.sh) */
-    if (LIST == 0) wv::set_priority(P.list0_prio >= 0 ? P.list0_prio : ((NB > 1 || *pmg::plan_promoted(P)) ? 1 : 0));
+    /* ... and slide's three-wavefront list 0 (round 6): with the double repeat beside its narrowphase the pushing env is the step's
+     * longest chain: 1.208 -> 1.240 M with priority (PMG_LIST0_PRIO=0 / 1, same library) */
+    if (LIST == 0) wv::set_priority(P.list0_prio >= 0 ? P.list0_prio : ((NB > 1 || list_spec_wave(LIST, CYL) || *pmg::plan_promoted(P)) ? 1 : 0));
     const int env = P.sched[2 + LIST * P.n_envs + b];
     const bool ok = pmg::step_env_core<NB, MAXC, CYL, list_two_waves(LIST, CYL), list_spec_wave(LIST, CYL)>(P, actions, env, L, lcs, true, sp);
     if (!ok && threadIdx.x == 0) {
