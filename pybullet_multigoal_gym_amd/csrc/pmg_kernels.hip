@@ -268,16 +268,19 @@ constexpr int LIST0_THREADS = PMG_LIST_TWO_WAVES ? 128 : 64;
 constexpr bool list_two_waves(int list, int cyl) { return list == 0 && PMG_LIST_TWO_WAVES != 0 && (cyl != 3 || PMG_LID_TWO_WAVES != 0); }
 /* ... and slide's list 0 with a THIRD one, which repeats the finger x puck pairs in double beside the helper's float narrowphase
  * (pmg::SpecLds; the rule that brings slide's single steps to the chaos floor, off the critical path) */
+/* (The chest tasks' cylinder repeats stay SERIAL: their steps are bound by wavefront slots, not by one chain -- a third wavefront on
+ * their list 0, with the plan sending every env whose gripper base can reach the chest there, measured 0.463 -> 0.263 M on chest_push,
+ * the lid task with helper + third wavefront 0.610 -> 0.366 M; profiles/r06_chest_repeat_rule_experiment.txt) */
 constexpr bool list_spec_wave(int list, int cyl) { return list_two_waves(list, cyl) && cyl == 1 && PMG_CYL_SPEC != 0 && PMG_CYL_PUSH_ALL != 0 && PMG_CYL_REDO64 != 0; }
 constexpr int list_threads(int list, int cyl) { return list_spec_wave(list, cyl) ? 192 : (list_two_waves(list, cyl) ? 128 : 64); }
-template <bool ON> struct SpecStore { __device__ static __forceinline__ pmg::SpecLds* get() { return nullptr; } };
-template <> struct SpecStore<true> { __device__ static __forceinline__ pmg::SpecLds* get() { __shared__ pmg::SpecLds s; return &s; } };
+template <bool ON, int CYL> struct SpecStore { __device__ static __forceinline__ pmg::SpecLds<CYL>* get() { return nullptr; } };
+template <int CYL> struct SpecStore<true, CYL> { __device__ static __forceinline__ pmg::SpecLds<CYL>* get() { __shared__ pmg::SpecLds<CYL> s; return &s; } };
 template <int NB, int MAXC, int LIST, int CYL = 0>
 __global__ void __launch_bounds__(list_threads(LIST, CYL), PMG_WAVES_PER_EU) pmg_k_step_list(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmg::ContactLds<NB, MAXC> L;
     __shared__ pmg::LaneTabStore lcs;
-    pmg::SpecLds* sp = SpecStore<list_spec_wave(LIST, CYL)>::get();
+    pmg::SpecLds<CYL>* sp = SpecStore<list_spec_wave(LIST, CYL), CYL>::get();
     const int b = (int)blockIdx.x;
     if (b >= P.sched[LIST]) return;
     /* issue priority for the wavefronts that are the long pole of the step: list 0 of the multi-block / chest tasks
@@ -339,8 +342,8 @@ hipError_t pmg_launch_step(const pmg::EnvParams& P, const float* d_actions, hipS
         PMG_FJ(hipEventRecord(ev_fork, s));
         PMG_FJ(hipStreamWaitEvent(side, ev_fork, 0));
         hipStream_t s0 = list0_first ? s : side, s1 = list0_first ? side : s;
-        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(LIST0_THREADS), 0, s0, P, d_actions);
-        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(list_two_waves(0, 3) ? 128 : 64), 0, s0, P, d_actions);
+        if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 2>), dim3(P.n_envs), dim3(list_threads(0, 2)), 0, s0, P, d_actions);
+        else hipLaunchKernelGGL((pmg_k_step_list<6, 48, 0, 3>), dim3(P.n_envs), dim3(list_threads(0, 3)), 0, s0, P, d_actions);
         if (!list0_first) PMG_FJ(hipEventRecord(ev_join, side));
         if (P.chest == 0) hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 2>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);
         else hipLaunchKernelGGL((pmg_k_step_list<6, MULTI_SMALL_MAXC, 1, 3>), dim3(P.n_envs), dim3(64), 0, s1, P, d_actions);

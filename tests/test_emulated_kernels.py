@@ -126,31 +126,42 @@ def test_emulated_object_off_the_table_lands_on_the_floor(emu_library, task, kw,
     env.close()
 
 
-def test_speculative_double_repeat_is_bit_identical_to_the_serial_repeat(emu_library, emu_library_serial_repeat):
-    """slide, the fingers pushing the puck (list 0: three wavefronts per workgroup -- env, float narrowphase, the finger x puck
-    pairs in double beside it): states and outputs EQUAL to the build that repeats those pairs serially behind the float pass
-    (round 5's PMG_CYL_PUSH_ALL layout), and the double results are really taken (the emulator counts them)."""
+@pytest.mark.parametrize('task', ['slide'])
+def test_speculative_double_repeat_is_bit_identical_to_the_serial_repeat(emu_library, emu_library_serial_repeat, task):
+    """List 0 of slide: three wavefronts per workgroup -- env, float narrowphase, and the finger x puck pairs, which are repeated in
+    double whenever they are in contact, computed beside it; the fingers pushing the puck.  States and outputs EQUAL to the build
+    that repeats those pairs serially behind the float pass (-DPMG_CYL_SPEC=0, round 5's layout), and the double results are
+    really taken (the emulator counts them)."""
     import ctypes as C
     N = 3
-    envs = [pmg.make_env(task='slide', num_envs=N, seed=3, seed_stride=1, _library=lib) for lib in (emu_library, emu_library_serial_repeat)]
+    kw = {} if task == 'slide' else {'num_block': 2}
+    envs = [pmg.make_env(task=task, num_envs=N, seed=3, seed_stride=1, _library=lib, **kw) for lib in (emu_library, emu_library_serial_repeat)]
     for e in envs:
         e.reset()
     st = envs[0].get_state().copy()
-    st[:, 64] = -0.52 + np.float32([0.0, 0.003, -0.002]); st[:, 65] = 0.045 + np.float32([0.0, -0.002, 0.003]); st[:, 66] = 0.170
-    st[:, 67:71] = [0, 0, 0, 1]; st[:, 71:77] = 0
+    if task == 'slide':
+        st[:, 64] = -0.52 + np.float32([0.0, 0.003, -0.002]); st[:, 65] = 0.045 + np.float32([0.0, -0.002, 0.003]); st[:, 66] = 0.170
+        st[:, 67:71] = [0, 0, 0, 1]; st[:, 71:77] = 0
+        acts = [[0, 1, 0], [0, 1, 0], [0.3, 1, 0]]
+    else:
+        acts = [[-1, 0.2 * k, 0.5] for k in (-1, 0, 1, 0, 1)]
     for e in envs:
         e.set_state(st)
     counter = C.CDLL(emu_library.path).pmge_cyl_spec_taken
     counter.restype = C.c_longlong
     before = counter()
-    for a in ([0, 1, 0], [0, 1, 0], [0.3, 1, 0]):
+    for t, a in enumerate(acts):
         a = np.tile(np.float32(a), (N, 1))
+        if task != 'slide':
+            a[:, 1] *= np.float32([1.0, 0.5, -1.0])
         outs = [e.step(a) for e in envs]
         assert all(np.array_equal(outs[0][0][k], outs[1][0][k]) for k in outs[0][0])
         assert np.array_equal(envs[0].get_state(), envs[1].get_state())
-        assert envs[0].handle.schedule()['prone'].size == N             # every env ran on list 0: the three-wavefront kernel
-    assert counter() - before > 50                                        # the fingers were on the puck: double results taken
-    assert (envs[0].get_state()[:, 65] > 0.06).all()
+        if task == 'slide' or t >= 1:
+            assert envs[0].handle.schedule()['prone'].size == N         # every env ran on list 0: the three-wavefront kernel
+    assert counter() - before > 50                                        # fingers on the puck / gripper base on the door: double results taken
+    if task == 'slide':
+        assert (envs[0].get_state()[:, 65] > 0.06).all()
     for e in envs:
         e.close()
 

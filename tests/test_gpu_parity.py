@@ -265,7 +265,7 @@ def test_constructed_chest_contacts_match_oracle(built, task):
     err = np.abs(o['achieved_goal'] - a64['achieved_goal']).max(1)        # door joint + block positions
     spread = np.abs(a32['achieved_goal'] - a64['achieved_goal']).max(1)
     # chest_pick_and_place: 2 of the 64 envs sit AT the bar (1.0e-3, 1.25e-3; chaos floor 0, the float32 oracle 3): the lid's
-    # handle between the closing fingers -- ABOVE_FLOOR of tests/test_gpu_tail_parity.py is the same effect in numbers
+    # handle between the closing fingers
     _max_or_count('%s constructed, door + blocks' % task, err, spread, extra=1 if task == 'chest_push' else 3)
     tip_err = np.abs(o['observation'][:, :3] - a64['observation'][:, :3]).max(1)
     _max_or_count('%s constructed, tip' % task, tip_err, np.abs(a32['observation'][:, :3] - a64['observation'][:, :3]).max(1))
@@ -886,6 +886,8 @@ def _sharded_equals_unsharded(lib, task, N, shards, T, kw=None):
     for t in range(T):
         a = rs.uniform(-1, 1, (N, A)).astype(np.float32)
         a[::2, 2] = -np.abs(a[::2, 2])                  # half of the batch keeps its fingers down: the class whose kernel used to depend on batch-wide counts
+        if task.startswith('chest'):
+            a[1::4, 0] = -np.abs(a[1::4, 0])            # a quarter heads for the chest: gripper base on its rim, fingers at the door (cylinder pairs, both lists)
         rf = full.step(a)
         rp = [e.step(a[k * n:(k + 1) * n]) for k, e in enumerate(parts)]
     for key in ('observation', 'policy_state', 'achieved_goal', 'desired_goal'):
@@ -898,15 +900,16 @@ def _sharded_equals_unsharded(lib, task, N, shards, T, kw=None):
         e.close()
 
 
-@pytest.mark.parametrize('task', ['push', 'pick_and_place', 'slide', 'reach', 'block_stack'])
+@pytest.mark.parametrize('task', ['push', 'pick_and_place', 'slide', 'reach', 'block_stack', 'chest_push', 'chest_pick_and_place'])
 @pytest.mark.parametrize('N,shards', [(512, 2), (4096, 8)])
 def test_sharded_batch_is_bit_identical_to_the_unsharded_batch(built, task, N, shards):
     """north_star: the batch shards trivially -- env i on GPU i // N_local is the env of the single-GPU run.  Which kernel an
     env of a one-object task runs in (packed LDS rows / one env per wavefront in row space: different float32 summation
     orders) is a function of the env's own state and of the task (EnvParams::fd_div), never of batch-wide counts (rounds 2-4:
     median 1e-5, up to 1 % of the envs beyond 1e-3 after 12 steps): 512 envs against 2 x 256 and 4096 against 8 x 512, 12
-    steps with half of the batch driven onto the table, outputs and state rows EQUAL."""
-    _sharded_equals_unsharded(None, task, N, shards, 12, {'num_block': 3} if task == 'block_stack' else {})
+    steps with half of the batch driven onto the table, outputs and state rows EQUAL.  The chest tasks (round 6): every chest kernel
+    applies ONE rule to the cylinder pairs (repeat in double when in contact), whichever list an env is on."""
+    _sharded_equals_unsharded(None, task, N, shards, 12, {'num_block': 3} if task == 'block_stack' else ({'num_block': 2} if task.startswith('chest') else {}))
 
 
 def test_two_wavefront_reach_kernel_is_bit_identical_to_the_one_wavefront_kernel(built):
