@@ -224,20 +224,15 @@ hipError_t pmg_launch_plan(const pmg::EnvParams& P, const float* d_actions, hipS
  * whose gripper works on the object run one per wavefront with the full 24-contact store in a SEPARATE launch
  * (pmg_k_step_list<1,24,0,CYL>, 16 KB) on the side stream, so that a batch in which most envs are of that kind keeps
  * the occupancy it had before the packing; surplus workgroups at the end of either grid exit at once */
-/* A helper wavefront for the packed kernel, too (PMG_OBJ4_TWO_WAVES=1: the narrowphase of the four envs beside their
- * dynamics), measured SLOWER: push 1.39 -> 1.10 M, slide 1.23 -> 0.95 M, pick_and_place 1.86 -> 1.25 M.  The 1024 packed
- * wavefronts of a 4096-env step sit one per SIMD; a second wavefront on every SIMD costs these kernels more than the
- * 5.6 k cycles per substep it takes off the chain (placement is even -- tools/probe_placement2.hip: two waves on each of
- * the 1024 SIMDs, never both of a workgroup on one -- and 40 KB of LDS per workgroup to force four per CU changes nothing) */
-#ifndef PMG_OBJ4_TWO_WAVES
-#define PMG_OBJ4_TWO_WAVES 0
-#endif
-constexpr int OBJ4_THREADS = PMG_OBJ4_TWO_WAVES ? 128 : 64;
+/* (A helper wavefront for the packed kernel, too -- the narrowphase of the four envs beside their dynamics -- measured SLOWER in round 3:
+ * push 1.39 -> 1.10 M, slide 1.23 -> 0.95 M, pick_and_place 1.86 -> 1.25 M: the 1024 packed wavefronts of a 4096-env step sit one per SIMD,
+ * and a second wavefront on every SIMD costs these kernels more than the 5.6 k cycles per substep it takes off the chain.  Removed.) */
+constexpr int OBJ4_THREADS = 64;
 template <bool CYL>
 __global__ void __launch_bounds__(OBJ4_THREADS, PMG_WAVES_PER_EU) pmg_k_step_obj4(pmg::EnvParams P, const float* __restrict__ actions)
 {
     __shared__ pmgp::ObjLds4 sm;
-    pmgp::step_group_obj<CYL, PMG_OBJ4_TWO_WAVES != 0>(P, actions, (int)blockIdx.x, sm);
+    pmgp::step_group_obj<CYL>(P, actions, (int)blockIdx.x, sm);
 }
 template <bool CYL>
 __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvParams P, const float* __restrict__ actions)
@@ -255,17 +250,11 @@ __global__ void __launch_bounds__(64, PMG_WAVES_PER_EU) pmg_k_redo_obj(pmg::EnvP
 constexpr int MULTI_SMALL_MAXC = 30;
 constexpr int LIST0_THREADS = PMG_LIST_TWO_WAVES ? 128 : 64;
 /* LIST 0 (the full contact store: the envs whose gripper works on an object -- the long pole of a batched step) runs
- * with TWO wavefronts per workgroup: the second one collides while the first computes the dynamics (helper_wave_loop) */
-#ifndef PMG_LIST_TWO_WAVES
-#define PMG_LIST_TWO_WAVES 1
-#endif
-/* ... except on the lid task (chest_pick_and_place, CYL == 3): a quarter of its batch is on list 0, the step is bound by the
+ * with TWO wavefronts per workgroup: the second one collides while the first computes the dynamics (helper_wave_loop) --
+ * except on the lid task (chest_pick_and_place, CYL == 3): a quarter of its batch is on list 0, the step is bound by the
  * wavefront slots, not by one chain, and the helper wavefronts cost more slots than they shorten chains (0.580 -> 0.609 M
- * without them; chest_push neutral, the block tasks lose 1 %: they keep theirs) */
-#ifndef PMG_LID_TWO_WAVES
-#define PMG_LID_TWO_WAVES 0
-#endif
-constexpr bool list_two_waves(int list, int cyl) { return list == 0 && PMG_LIST_TWO_WAVES != 0 && (cyl != 3 || PMG_LID_TWO_WAVES != 0); }
+ * without them, round 4; with them 0.614 -> 0.585 M, round 5; chest_push neutral, the block tasks lose 1 % without: they keep theirs) */
+constexpr bool list_two_waves(int list, int cyl) { return list == 0 && PMG_LIST_TWO_WAVES != 0 && cyl != 3; }
 /* ... and slide's list 0 with a THIRD one, which repeats the finger x puck pairs in double beside the helper's float narrowphase
  * (pmg::SpecLds; the rule that brings slide's single steps to the chaos floor, off the critical path) */
 /* (The chest tasks' cylinder repeats stay SERIAL: their steps are bound by wavefront slots, not by one chain -- a third wavefront on

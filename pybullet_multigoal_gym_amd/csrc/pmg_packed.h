@@ -52,12 +52,8 @@ __device__ __forceinline__ bool substep_free(const EnvParams& P, const LaneConst
     PMGP_T(3);
     float rq = l < NJ ? tau - h : 0.f;
     float qdd = 0.f;
-#if PMG_FMA9
-    qdd = wr::fma9_lanes_r0(qdd, minv, rq);
-#else
 #pragma unroll
     for (int j = 0; j < NJ; j++) qdd += minv[j] * wr::bcast_r0(rq, j);
-#endif
     qd += DT * qdd;
     NcRows r;
     build_nc_rows(c, minv, q, qd, mtarget, mimp, r);
@@ -185,8 +181,7 @@ struct ObjLds4 { /* LDS of a packed workgroup: four contact stores + the lane-co
     ContactLds<1, PACKED_MAXC> Ls[4];
     LaneTabStore lcs;
 };
-/* TWO: 128-thread workgroups -- wavefront 1 runs the narrowphase of the four envs beside wavefront 0's dynamics (helper_wave_loop) */
-template <bool CYL, bool TWO = false>
+template <bool CYL>
 __device__ __forceinline__ void step_group_obj(const EnvParams& P, const float* actions, int group, ObjLds4& sm)
 {
     ContactLds<1, PACKED_MAXC>* Ls = sm.Ls;
@@ -196,7 +191,7 @@ __device__ __forceinline__ void step_group_obj(const EnvParams& P, const float* 
     const int idx = 4 * group + wr::row();
     const bool have = idx < n1;                        /* surplus rows shadow the last env and write nothing */
     const int env = P.sched[2 + P.n_envs + (have ? idx : n1 - 1)];
-    const bool ok = step_env_core<1, PACKED_MAXC, CYL, TWO>(P, actions, env, Ls[wr::row()], lcs, have);
+    const bool ok = step_env_core<1, PACKED_MAXC, CYL>(P, actions, env, Ls[wr::row()], lcs, have);
     if (have && !ok && wr::lane() == 0) {
         int* redo = P.sched + 2 + 2 * P.n_envs;
         int slot = atomicAdd(redo, 1);

@@ -24,9 +24,6 @@ __device__ __forceinline__ float load(const float* p) { return __builtin_nontemp
 __device__ __forceinline__ void store(unsigned int v, unsigned int* p) { __builtin_nontemporal_store(v, p); }
 }  // namespace nt
 
-#ifndef PMG_FMA9
-#define PMG_FMA9 0
-#endif
 #ifndef PMG_DOT6_SPLIT
 #define PMG_DOT6_SPLIT 0
 #endif
@@ -254,44 +251,6 @@ __device__ __forceinline__ void gj9_eliminate_r0_c(float* a, float f)
 #else
 #pragma unroll
     for (int k = 1; k < 9; k++) { const int j = (P + k) % 9; a[j] = fmaf(bcast_r0_c<P>(a[j]), f, a[j]); }
-#endif
-}
-/* acc += sum_j c[j] * v(lane j of my row), j < 9 in index order: M^-1 times a joint-space vector held one entry per lane */
-__device__ __forceinline__ float fma9_lanes_r0(float acc, const float* c, float v)
-{
-#if !defined(PMG_NO_R0_DPP) && !defined(PMG_NO_DPP_FMAC) && PMG_FMA9 == 2
-    float a1, a2;   /* three interleaved chains */
-    asm("s_nop 1\n\t"
-        "v_fmac_f32_dpp %0, %3, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %1, %3, %5 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_mul_f32_dpp %2, %3, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %3, %7 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %3, %8 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %3, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %3, %10 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %1, %3, %11 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %2, %3, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc), "=&v"(a1), "=&v"(a2)
-        : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]));
-    return acc + (a1 + a2);
-#elif !defined(PMG_NO_R0_DPP) && !defined(PMG_NO_DPP_FMAC)
-    asm("s_nop 1\n\t"
-        "v_fmac_f32_dpp %0, %1, %2 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %3 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %5 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %8 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_fmac_f32_dpp %0, %1, %10 row_newbcast:8 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc)
-        : "v"(v), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "v"(c[8]));
-    return acc;
-#else
-#pragma unroll
-    for (int j = 0; j < 9; j++) acc = fmaf(bcast_r0(v, j), c[j], acc);
-    return acc;
 #endif
 }
 /* One Gauss-Jordan pivot of a 6 x 6 system [A | e], lane a < 6 = row a (the IK's damped least squares): every row loses
@@ -592,7 +551,6 @@ template <int P>
 __device__ __forceinline__ void gj6_eliminate_r0_c(float* a, float& e, float f) { wv::gj6_eliminate_r0_c<P>(a, e, f); }
 __device__ __forceinline__ float dot6_lanes_r0(const float* c, float v) { return wv::dot6_lanes_r0(c, v); }
 __device__ __forceinline__ float fsqrt(float x) { return wv::fsqrt(x); }
-__device__ __forceinline__ float fma9_lanes_r0(float acc, const float* c, float v) { return wv::fma9_lanes_r0(acc, c, v); }
 __device__ __forceinline__ float add_shr2_bank2(float y, float x) { return wv::add_shr2_bank2(y, x); }
 template <int N>
 __device__ __forceinline__ float row_shr(float v, float fill) { return wv::row_shr<N>(v, fill); }

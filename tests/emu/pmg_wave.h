@@ -204,11 +204,6 @@ inline float dot6_lanes_r0(const float* c, float v)
     return acc;
 }
 inline float fsqrt(float x) { return sqrtf(x); }
-inline float fma9_lanes_r0(float acc, const float* c, float v)
-{
-    for (int j = 0; j < 9; j++) acc = fmaf(bcast(v, j), c[j], acc);
-    return acc;
-}
 inline float add_shr2_bank2(float y, float x)
 {
     const float y2 = row_shr<2>(y, 0.f);
@@ -324,11 +319,6 @@ inline float dot6_lanes_r0(const float* c, float v)
     return acc;
 }
 inline float fsqrt(float x) { return sqrtf(x); }
-inline float fma9_lanes_r0(float acc, const float* c, float v)
-{
-    for (int j = 0; j < 9; j++) acc = fmaf(bcast(v, j), c[j], acc);
-    return acc;
-}
 inline float add_shr2_bank2(float y, float x)
 {
     const float y2 = row_shr<2>(y, 0.f);

@@ -13,6 +13,9 @@ task = sys.argv[1] if len(sys.argv) > 1 else 'chest_push'
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 kw = {'num_block': 4} if task in ('block_stack', 'block_rearrange', 'chest_push', 'chest_pick_and_place') else {}
+if os.environ.get('PMG_TF_LIB'):                       # (kernel A/B: another build of the library, as tools/teacher_forced.py)
+    from pybullet_multigoal_gym_amd._lib import PmgLibrary
+    kw['_library'] = PmgLibrary(os.environ['PMG_TF_LIB'])
 env = pmg.make_env(task=task, gripper='parallel_jaw', num_envs=N, seed=0, **kw)
 h = env.handle
 T = 50
