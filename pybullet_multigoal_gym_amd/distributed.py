@@ -202,12 +202,28 @@ def job_token(addr='127.0.0.1'):
     import hashlib
     tok = os.environ.get('PMG_RDV_TOKEN')
     if tok is None:
+        # rank 0 is by definition local to MASTER_ADDR, so the address test below cannot see a multi-node job from there: the
+        # launcher's own count can (torchrun exports LOCAL_WORLD_SIZE).  Without a shared secret a multi-node job is refused on
+        # EVERY rank, and a single-node one listens on loopback only (Rendezvous: _derived_token_endpoint)
+        lws, ws = os.environ.get('LOCAL_WORLD_SIZE'), os.environ.get('WORLD_SIZE')
+        if lws and ws and int(ws) > int(lws):
+            raise RuntimeError('rendezvous of a multi-node job (WORLD_SIZE %s > LOCAL_WORLD_SIZE %s): set PMG_RDV_TOKEN to a secret shared by '
+                               'the ranks -- the derived token is guessable and only protects a single-node rendezvous on loopback' % (ws, lws))
         if not _is_local_address(addr) and os.environ.get('PMG_RDV_SINGLE_NODE') != '1':
             raise RuntimeError('rendezvous on %s, which is not an address of this machine: set PMG_RDV_TOKEN to a secret shared by '
                                'the ranks (the derived token only protects a single-node rendezvous against stale peers; a '
                                'single-node launcher whose master address does not resolve here can say PMG_RDV_SINGLE_NODE=1)' % addr)
         tok = '|'.join(os.environ.get(k, '') for k in ('TORCHELASTIC_RUN_ID', 'MASTER_ADDR', 'MASTER_PORT', 'PMG_RDV_PORT', 'WORLD_SIZE'))
     return hashlib.sha256(('pmg-rdv:' + tok).encode()).digest()
+
+
+def _derived_token_endpoint(addr):
+    """Where the rendezvous really listens / connects.  With the DERIVED (guessable) token the job is single-node by job_token()'s
+    checks, so the listener stays on loopback whatever name the launcher exported as MASTER_ADDR: nobody off this machine can
+    reach it.  With PMG_RDV_TOKEN (a shared secret) the address is used as given."""
+    if 'PMG_RDV_TOKEN' in os.environ:
+        return '127.0.0.1' if addr == 'localhost' else addr
+    return '127.0.0.1'
 
 
 class Rendezvous:
@@ -229,11 +245,11 @@ class Rendezvous:
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr if addr not in ('localhost',) else '127.0.0.1', port))
+            token = job_token(addr)                 # (raises for a multi-node job without PMG_RDV_TOKEN before anything listens)
+            srv.bind((_derived_token_endpoint(addr), port))
             srv.listen(self.world)
             srv.settimeout(timeout)
             by_rank = {}
-            token = job_token(addr)
             deadline = time.time() + timeout
             rejected = []
 
@@ -290,10 +306,11 @@ class Rendezvous:
             srv.close()
             self.peers = [by_rank[r] for r in range(1, self.world)]
         else:
+            token = job_token(addr)                 # (first: a multi-node job without PMG_RDV_TOKEN fails here, not in a connect timeout)
             deadline = time.time() + timeout
             while True:
                 try:
-                    s = socket.create_connection((addr, port), timeout=5.0)
+                    s = socket.create_connection((_derived_token_endpoint(addr), port), timeout=5.0)
                     break
                 except OSError:
                     if time.time() > deadline:
@@ -301,7 +318,7 @@ class Rendezvous:
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(timeout)
-            _send(s, [job_token(addr), self.rank])
+            _send(s, [token, self.rank])
             # the handshake: rank 0 answers the hello with ACK or NAK before any collective -- no sentinel values inside
             # collective payloads, and a refused rank learns it here, not from a broken pipe in its first all-gather
             try:

@@ -344,8 +344,18 @@ def test_job_token_accepts_a_hostname_master_address_of_this_machine(monkeypatch
     monkeypatch.setenv('PMG_RDV_SINGLE_NODE', '1')
     assert len(D.job_token('nowhere.invalid')) == 32
     monkeypatch.delenv('PMG_RDV_SINGLE_NODE')
+    # rank 0 is always local to MASTER_ADDR: a MULTI-NODE job is recognised by the launcher's own counts and refused on every rank
+    # without a shared secret; with the derived (guessable) token the rendezvous listens and connects on loopback only
+    monkeypatch.setenv('WORLD_SIZE', '16'); monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    with pytest.raises(RuntimeError, match='multi-node'):
+        D.job_token('node17.cluster.example')
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '16')
+    assert len(D.job_token('node17.cluster.example')) == 32
+    assert D._derived_token_endpoint('node17.cluster.example') == '127.0.0.1'
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
     monkeypatch.setenv('PMG_RDV_TOKEN', 's3cret')
     assert D.job_token('head.cluster.example') == D.job_token('127.0.0.1')
+    assert D._derived_token_endpoint('head.cluster.example') == 'head.cluster.example'
 
 
 def test_product_never_imports_torch():
