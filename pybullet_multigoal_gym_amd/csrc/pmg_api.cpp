@@ -117,6 +117,7 @@ struct pmg_env {
     int ev_n = 0;
     int ev_every = 1;                 /* events around every ev_every-th batched step (pmg_timing_every) */
     long long step_count = 0;
+    long long plans = 0;              /* batched steps planned so far (parity of the longest-first threshold words) */
     double ev_ms = 0.0, ev_min = 0.0, ev_max = 0.0;
     long long ev_launches = 0;
     bool ever_reset = false;
@@ -136,6 +137,10 @@ struct pmg_env {
     int last_gather = -1;
     char err[512] = "";
 };
+
+#ifndef PMG_LPT_PERMILLE_DEFAULT
+#define PMG_LPT_PERMILLE_DEFAULT 400   /* the slowest 40 % of the fast-path list lead it (profiles/r06_lpt_quantile_sweep.txt) */
+#endif
 
 namespace {
 
@@ -386,11 +391,26 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
          * and chest_pick_and_place-4 0.57 -> 0.58 M at 85 k / 70 k, block_stack-4 0.79 -> 0.80 M at 60 k; block_rearrange
          * loses (0.70 -> 0.61 M: there the fingers-down grouping it replaces IS the better order) and keeps it off.
          * Results do not depend on the order of a launch list, only the schedule does */
-        e->P.lpt_thresh = dims.num_envs < 4096 ? 0 : (e->cfg.task == PMG_TASK_CHEST_PUSH ? 85000 : (e->cfg.task == PMG_TASK_CHEST_PICK_AND_PLACE ? 70000 :
-                          (e->cfg.task == PMG_TASK_BLOCK_STACK ? 60000 : 0)));
-        if (const char* lt = getenv("PMG_LPT_CYCLES")) e->P.lpt_thresh = atoi(lt);
+        /* Round 6: the threshold is no longer a shader-clock count tuned per task on one part at one batch size (85 000 / 70 000 / 60 000):
+         * the plan derives it every step as the cycle count above which the slowest lpt_permille / 1000 of the fast-path envs lay in
+         * the last step (pmg_k_plan_count's histogram, pmg_k_plan_scatter).  PMG_LPT_PERMILLE overrides the share, PMG_LPT_CYCLES > 0
+         * forces a constant, PMG_LPT_CYCLES=0 switches the order off */
+        e->P.lpt_thresh = 0;
+        /* share of the list that leads it, measured (profiles/r06_lpt_quantile_sweep.txt): chest tasks flat between 350 and 450 (0.403 /
+         * 0.545 M, the tuned constants' 0.402 / 0.547 M), block_stack best at 450 (0.804 M; constant 60 000: 0.818 M), block_rearrange loses
+         * with any (0.69 -> 0.60 M: its fingers-down grouping is the better order) and keeps the rule off */
+        e->P.lpt_permille = dims.num_envs < 4096 ? 0 : ((e->cfg.task == PMG_TASK_CHEST_PUSH || e->cfg.task == PMG_TASK_CHEST_PICK_AND_PLACE) ? PMG_LPT_PERMILLE_DEFAULT :
+                                                        (e->cfg.task == PMG_TASK_BLOCK_STACK ? PMG_LPT_PERMILLE_DEFAULT + 50 : 0));
+        e->P.lpt_parity = 0;
+        e->P.lpt_state = nullptr;
+        if (const char* lq = getenv("PMG_LPT_PERMILLE")) e->P.lpt_permille = atoi(lq);
+        if (const char* lt = getenv("PMG_LPT_CYCLES")) { e->P.lpt_thresh = atoi(lt); if (e->P.lpt_thresh <= 0) e->P.lpt_permille = 0; }
         const char* ec = getenv("PMG_ENV_CYCLES");
-        if ((ec && atoi(ec) != 0) || (e->P.lpt_thresh > 0 && e->nb > 1)) {
+        if (e->nb > 1 && e->P.lpt_permille > 0 && e->P.lpt_thresh <= 0) {
+            CREATE_TRY(hipMalloc((void**)&e->P.lpt_state, (2 + pmg::LPT_BINS) * sizeof(int)));
+            CREATE_TRY(hipMemset(e->P.lpt_state, 0, (2 + pmg::LPT_BINS) * sizeof(int)));
+        }
+        if ((ec && atoi(ec) != 0) || ((e->P.lpt_thresh > 0 || e->P.lpt_permille > 0) && e->nb > 1)) {
             CREATE_TRY(hipMalloc((void**)&e->P.env_cycles, 2 * N * sizeof(int)));
             CREATE_TRY(hipMemset(e->P.env_cycles, 0, 2 * N * sizeof(int)));
         }
@@ -432,7 +452,7 @@ int pmg_create(const pmg_config* cfg, pmg_env** out)
     {   /* the tuning / experiment switches this library reads from the environment change its schedule (never its results' meaning):
          * a stray one in a user's shell -- PMG_PACKED=0 halves the throughput -- must not go unnoticed: ONE line on stderr per handle */
         static const char* const kSwitches[] = {"PMG_PACKED", "PMG_REACH_TWO_WAVES", "PMG_NEAR_R", "PMG_CHEST_REACH", "PMG_FD_DIV", "PMG_WAVE_BUDGET",
-                                                "PMG_LPT_CYCLES", "PMG_ENV_CYCLES", "PMG_LIST0_PRIO", "PMG_LIST0_FIRST", "PMG_PLAN_TWO_PASS",
+                                                "PMG_LPT_CYCLES", "PMG_LPT_PERMILLE", "PMG_ENV_CYCLES", "PMG_LIST0_PRIO", "PMG_LIST0_FIRST", "PMG_PLAN_TWO_PASS",
                                                 "PMG_REWARD_GENERIC"};
         std::string active;
         for (const char* name : kSwitches)
@@ -450,7 +470,7 @@ void pmg_destroy(pmg_env* e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);   /* an overlapped all-gather in flight reads out2[] through e->comm */
     if (e->comm) ncclCommDestroy(e->comm);
-    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); if (e->out2[1]) { (void)hipFree(e->out2[0]); (void)hipFree(e->out2[1]); } else (void)hipFree(e->P.out); (void)hipFree(e->P.sched); if (e->P.env_cycles) (void)hipFree(e->P.env_cycles);
+    (void)hipFree(e->P.hot); (void)hipFree(e->P.cold); (void)hipFree(e->P.goal); (void)hipFree(e->P.curr); (void)hipFree(e->P.blocks); (void)hipFree(e->P.rng); if (e->out2[1]) { (void)hipFree(e->out2[0]); (void)hipFree(e->out2[1]); } else (void)hipFree(e->P.out); (void)hipFree(e->P.sched); if (e->P.env_cycles) (void)hipFree(e->P.env_cycles); if (e->P.lpt_state) (void)hipFree(e->P.lpt_state);
     (void)hipFree(e->d_actions); (void)hipFree(e->d_mask);
     (void)hipFree(e->d_rw_ag); (void)hipFree(e->d_rw_dg); (void)hipFree(e->d_rw_r); (void)hipFree(e->d_rw_ok);
     if (e->h_packed) (void)hipHostFree(e->h_packed);
@@ -537,6 +557,7 @@ int pmg_step_device(pmg_env* e, const float* d_actions)
     const bool timed = (e->step_count++ % e->ev_every) == 0;
     if (timed && e->ev_n == EVENT_POOL) drain_events(e);
     int i = timed ? e->ev_n++ : 0;
+    e->P.lpt_parity = (int)(e->plans++ & 1);
     HIP_TRY(e, pmg_launch_plan(e->P, d_actions, e->stream)); /* launch-order plan (13 us), outside the step-kernel timer */
     int mode = e->packed;
     /* reach: steps that have contact-prone envs run the two-wavefront kernel while the contact-free list is at most one

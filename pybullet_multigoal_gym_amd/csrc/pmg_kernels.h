@@ -49,7 +49,10 @@ struct EnvParams {
                         lists, [2 + 2N] the redo count and behind it the redo list of the fast paths (pmg_packed.h); then
                         [3 + 3N ..) the per-workgroup class counts of the two-pass plan (3 per 1024 envs) and one last word:
                         did the plan promote the fingers-down class to list 0 (plan_promoted()) */
-    int lpt_thresh;  /* > 0 (and env_cycles kept): several blocks, fast-path list ordered longest-first -- envs whose wavefront took more than this many cycles / 64 in the PREVIOUS step lead the list (plan_class) */
+    int lpt_thresh;  /* > 0 (and env_cycles kept): several blocks, fast-path list ordered longest-first -- envs whose wavefront took more than this many cycles / 64 in the PREVIOUS step lead the list (plan_class).  A constant only as an override (PMG_LPT_CYCLES) */
+    int lpt_permille; /* > 0: the threshold is DERIVED ON THE DEVICE -- the cycle count above which the slowest lpt_permille / 1000 of the fast-path list's envs lay in the last step (a 128-bin histogram the plan keeps: lpt_state): no per-part, per-batch-size tuned constants */
+    int lpt_parity;   /* which of the two threshold words this step's plan reads (it writes the other one for the next step) */
+    int* lpt_state;   /* [2 + LPT_BINS]: thresholds (two, by step parity) and the histogram of env_cycles over the fast-path envs */
     int* env_cycles; /* diagnostics (NULL unless PMG_ENV_CYCLES=1 at creation): [N, 2] shader cycles / 64 the env's wavefront spent
                         in its last step, and the largest contact count any of its substeps saw */
 #ifdef PMG_PROFILE
@@ -207,11 +210,20 @@ constexpr int PLAN_TWO_PASS_MIN = 4096;  /* ... and by default only below here: 
 /* class of an env for the launch order: 0 = first list (one env per wavefront, full contact store), 1 / 2 = second
  * list (fast path).  With free objects the fast-path envs are grouped by whether the fingers are down at the table
  * (class 1) or up (class 2): the four envs of a packed wavefront then mostly walk the same contact code paths */
+/* longest first: the threshold of this step -- the override, or what the previous step's plan derived from its histogram */
+constexpr int LPT_BINS = 128, LPT_BIN_SHIFT = 11;          /* bins of 2048 x 64 cycles = 0.06 ms; 128 of them: 7.6 ms */
+__device__ __forceinline__ int lpt_threshold(const EnvParams& P)
+{
+    return P.lpt_thresh > 0 ? P.lpt_thresh : (P.lpt_permille > 0 ? P.lpt_state[P.lpt_parity] : 0);
+}
 __device__ __forceinline__ int plan_class(const EnvParams& P, const float* actions, int env, const PlanIn& in)
 {
     if (contact_prone(P, actions, env, in)) return 0;
     if (P.nb == 0) return 1;
-    if (P.nb > 1 && P.lpt_thresh > 0 && P.env_cycles) return P.env_cycles[2 * env] > P.lpt_thresh ? 1 : 2;
+    if (P.nb > 1 && P.env_cycles && (P.lpt_thresh > 0 || P.lpt_permille > 0)) {
+        const int thr = lpt_threshold(P);
+        if (thr > 0) return P.env_cycles[2 * env] > thr ? 1 : 2;
+    }
     float z = in.ee[2];
     float zn = fminf(fmaxf(z + in.a[2] * 0.01f, P.ee_lo[2]), P.ee_hi[2]);
     return fminf(z, zn) < P.ee_lo[2] + 0.012f ? 1 : 2;
@@ -332,8 +344,19 @@ __device__ __forceinline__ void plan_count(const EnvParams& P, const float* acti
     const int cls = env < P.n_envs ? plan_class(P, actions, env) : -1;
     const unsigned long long m0 = wv::ballot(cls == 0), m1 = wv::ballot(cls == 1), m2 = wv::ballot(cls == 2);
     if (lane == 0) { atomicAdd(&acc[0], __popcll(m0)); atomicAdd(&acc[1], __popcll(m1)); atomicAdd(&acc[2], __popcll(m2)); }
+    const bool lpt = P.nb > 1 && P.lpt_permille > 0 && P.env_cycles && P.lpt_thresh <= 0;   /* (uniform) */
+    __shared__ int hist[LPT_BINS];
+    if (lpt) {
+        if (tid < LPT_BINS) hist[tid] = 0;
+        __syncthreads();
+        if (cls > 0) {                                       /* a fast-path env: its wavefront time of the last step */
+            const int b = P.env_cycles[2 * env] >> LPT_BIN_SHIFT;
+            atomicAdd(&hist[b < LPT_BINS ? b : LPT_BINS - 1], 1);
+        }
+    }
     __syncthreads();
     if (tid < 3) plan_wg_counts(P)[3 * (int)blockIdx.x + tid] = acc[tid];
+    if (lpt && tid < LPT_BINS && hist[tid]) atomicAdd(&P.lpt_state[2 + tid], hist[tid]);
 }
 __device__ __forceinline__ void plan_scatter(const EnvParams& P, const float* actions)
 {
@@ -373,6 +396,21 @@ __device__ __forceinline__ void plan_scatter(const EnvParams& P, const float* ac
         P.sched[1] = promote ? n2all : n1 + n2all;
         P.sched[2 + 2 * P.n_envs] = 0; /* redo list of the fast paths starts empty */
         *plan_promoted(P) = promote ? 1 : 0;
+    }
+    if (wg == 0 && P.nb > 1 && P.lpt_permille > 0 && P.env_cycles && P.lpt_thresh <= 0) {
+        /* the NEXT step's threshold (the other parity's word: workgroups of this launch still read this step's): walk the
+         * histogram of the fast-path envs' cycles from the top until the slowest lpt_permille / 1000 of them are counted */
+        __shared__ int hs[LPT_BINS];
+        if (tid < LPT_BINS) { hs[tid] = P.lpt_state[2 + tid]; P.lpt_state[2 + tid] = 0; }
+        __syncthreads();
+        if (tid == 0) {
+            long long total = 0;
+            for (int b = 0; b < LPT_BINS; b++) total += hs[b];
+            long long acc2 = 0;
+            int b = LPT_BINS - 1;
+            for (; b > 0; b--) { acc2 += hs[b]; if (acc2 * 1000 >= total * P.lpt_permille) break; }
+            P.lpt_state[P.lpt_parity ^ 1] = (hs[0] == total) ? 0 : (b << LPT_BIN_SHIFT);   /* (nothing measured yet: off) */
+        }
     }
 }
 __device__ __forceinline__ int scheduled_env(const EnvParams& P, int block)
