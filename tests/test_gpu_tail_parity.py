@@ -88,17 +88,19 @@ def test_teacher_forced_outliers_against_the_chaos_floor(built, task):
         assert d['p50'] <= 2e-6, (task, name, d)
 
 
-def test_slide_single_steps_at_the_chaos_floor_large_sample(built):
-    """The same comparison for slide at four times the sample -- 4096 envs x 50 random-policy steps = 204 800 teacher-forced single
-    steps: rounds 1-5 passed the 51 200-step bar with 15-25 gross puck steps hidden inside `2 x floor + 3` plus a cap; at this
-    sample the floor is 0 and a build without the double repeat of the finger x puck contacts measures 25.  Bar: <= 3 + 2 x floor on
-    every quantity (measured: puck 3, tip 0, joints 1; floor 0 / 0 / 1)."""
+@pytest.mark.parametrize('task', RELATIVE)
+def test_single_steps_at_the_chaos_floor_large_sample(built, task):
+    """The same comparison at four times the sample -- 4096 envs x 50 random-policy steps = 204 800 teacher-forced single steps:
+    rounds 1-5 passed the 51 200-step bar with slide's 15-25 gross puck steps hidden inside `2 x floor + 3` plus a cap; at this sample
+    slide's floor is 0 and a build without the double repeat of the finger x puck contacts measures 25 (chest_push joints 19 against a
+    floor of 3.5, chest_pick_and_place joints 56 against 14).  Bar: <= 2 x floor + 3 on every quantity (measured, round 6: slide puck
+    3 / tip 0 / joints 1; chest_push 1 / 0 / 5, door 0; chest_pick_and_place 0 / 6 / 18, door 9)."""
     import teacher_forced as TF
-    dev = TF.run('slide', 4096, 50, {}, device=True, threads=oracle_lib.usable_threads(), perturb=2)
-    assert dev['flag_mismatches'] <= 4
-    for name in ('block_pos', 'tip_pos', 'q_arm'):
+    dev = TF.run(task, 4096, 50, _kw(task), device=True, threads=oracle_lib.usable_threads(), perturb=2)
+    assert dev['flag_mismatches'] <= 8
+    for name in ('block_pos', 'tip_pos', 'q_arm') + (('door_q',) if task.startswith('chest') else ()):
         d, c = dev['stats'][name], dev['chaos'][name]
-        print('slide x 204 800', name, 'device', d['n_gt_1e-3'], 'floor', c['floor_per_perturbed_oracle'])
+        print(task, 'x 204 800', name, 'device', d['n_gt_1e-3'], 'floor', c['floor_per_perturbed_oracle'])
         assert d['n'] == 204800
         assert d['n_gt_1e-3'] <= 2 * c['floor'] + 3, (name, d, c)
         assert d['p99'] <= 2e-5 and d['p50'] <= 2e-6, (name, d)
